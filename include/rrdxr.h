@@ -1,0 +1,198 @@
+/*
+ * rrdxr.h -- C ABI of the MI355X-native refraction ray tracer.
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference
+ * (bottledspace/refraction-raytracing-dxr) has no FFI of its own: the path sits
+ * behind D3D12 command-list calls issued by RefractionDemo.cpp.  Every entry
+ * point below cites the reference call it replaces (file:line relative to the
+ * reference tree).  Plain C types only; every function returns an rr_status
+ * (never aborts, never throws); one caller thread per context, exactly like the
+ * reference's single-threaded frame loop (RefractionDemo.cpp:557-612).
+ *
+ * The library needs a gfx950 device for every rr_* call that takes a context;
+ * there is no CPU fallback.  The rr_host_* helpers (OBJ loader, camera math,
+ * image decode) are pure host code.
+ */
+#ifndef RRDXR_H
+#define RRDXR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RRDXR_ABI_VERSION 1
+
+typedef enum rr_status {
+    RR_OK = 0,
+    RR_ERR_INVALID_ARGUMENT = 1,
+    RR_ERR_NO_DEVICE = 2,        /* no gfx950 device / HIP runtime failure at create */
+    RR_ERR_DEVICE = 3,           /* a HIP call failed; rr_last_error has the text */
+    RR_ERR_OUT_OF_MEMORY = 4,
+    RR_ERR_STATE = 5,            /* call order violated (e.g. dispatch before build) */
+    RR_ERR_IO = 6,
+    RR_ERR_UNSUPPORTED = 7,      /* parameter outside what the kernels are built for */
+    RR_ERR_TRAVERSAL_OVERFLOW = 8/* a traversal stack overflowed: result invalid */
+} rr_status;
+
+/* Vertex record: Mesh.hpp:6-11 == RayTracing.hlsl:5-9.  32 bytes, stride of t2. */
+typedef struct rr_vertex {
+    float position[3];
+    float norm[3];
+    float uv[2];
+} rr_vertex;
+
+/* SceneConstants: RayTracing.hlsl:1-4, CPU twin RefractionDemo.cpp:12-15.
+ * proj_inv holds the 64 bytes exactly as the CPU writes them (DirectXMath row-major);
+ * the shader reads them column-major, which the kernels reproduce. */
+typedef struct rr_scene_constants {
+    float proj_inv[16];
+    float camera_loc[4];
+} rr_scene_constants;
+
+/* Mirrors the 64-byte D3D12_RAYTRACING_INSTANCE_DESC filled at RefractionDemo.cpp:324-334. */
+typedef struct rr_instance_desc {
+    float    transform[12];       /* 3x4 row-major object->world */
+    uint32_t instance_id_mask;    /* InstanceID:24 | InstanceMask:8  */
+    uint32_t hitgroup_flags;      /* InstanceContributionToHitGroupIndex:24 | Flags:8 */
+    uint64_t blas;                /* mesh id from rr_upload_mesh (stands for the BLAS GPU VA) */
+} rr_instance_desc;
+
+#define RR_INSTANCE_FLAG_TRIANGLE_CULL_DISABLE            0x1u
+#define RR_INSTANCE_FLAG_TRIANGLE_FRONT_COUNTERCLOCKWISE  0x2u
+
+/* The literals of the shader become parameters whose defaults are those literals. */
+typedef struct rr_dispatch_params {
+    int32_t max_refract;          /* 5      RayTracing.hlsl:82  (payload.count < 5) */
+    int32_t max_reflect;          /* 2      RayTracing.hlsl:110 (payload.count < 2); <= 8 */
+    float   ior;                  /* 1.3    RayTracing.hlsl:95 */
+    float   tmin_primary;         /* 1e-4   RayTracing.hlsl:52 */
+    float   tmax_primary;         /* 100    RayTracing.hlsl:53 */
+    float   tmin_secondary;       /* 1e-3   RayTracing.hlsl:99,114 */
+    float   tmax_secondary;       /* 1000   RayTracing.hlsl:100,115 */
+    uint32_t flags;               /* RR_DISPATCH_* */
+} rr_dispatch_params;
+
+#define RR_DISPATCH_FLOAT_OUTPUT  0x1u  /* also keep the un-quantised float4 colour per pixel */
+#define RR_DISPATCH_COLLECT_STATS 0x2u  /* instrumented kernel: node/triangle/hit/miss counters */
+
+typedef struct rr_stats {
+    uint64_t rays;                /* every TraceRay: primary + secondary */
+    uint64_t primary;
+    uint64_t secondary;
+    uint64_t hits;
+    uint64_t misses;
+    uint64_t terminal_hits;       /* ClosestHit with count >= max_refract */
+    uint64_t tir;                 /* RefractRay returned false */
+    uint64_t node_visits;         /* internal BVH nodes fetched (64 B each)  */
+    uint64_t tri_tests;           /* triangle records fetched (48 B each)    */
+    uint64_t pixels;              /* pixels this context rendered in the last dispatch */
+    uint32_t stats_valid;         /* 1 if the last dispatch ran with RR_DISPATCH_COLLECT_STATS */
+    uint32_t traversal_overflow;  /* sticky error flag of the last dispatch */
+    uint32_t bvh_depth;           /* deepest BLAS / TLAS leaf */
+    uint32_t reserved;
+} rr_stats;
+
+typedef struct rr_ray {
+    float origin[3]; float tmin;
+    float dir[3];    float tmax;
+    uint32_t flags;               /* RR_RAY_FLAG_* */
+    uint32_t pad[3];
+} rr_ray;
+
+#define RR_RAY_FLAG_CULL_BACK_FACING_TRIANGLES  0x10u   /* DXR RAY_FLAG values */
+#define RR_RAY_FLAG_CULL_FRONT_FACING_TRIANGLES 0x20u
+
+typedef struct rr_hit {
+    float    t, u, v;             /* u weights vertex 1, v weights vertex 2 (RayTracing.hlsl:86) */
+    uint32_t prim;                /* PrimitiveIndex() */
+    uint32_t inst;                /* index into the rr_build_tlas array */
+    uint32_t hit;                 /* 0 = miss */
+} rr_hit;
+
+typedef struct rr_context rr_context;
+
+/* ---- device / lifetime: createDevice, RefractionDemo.cpp:142-172 ------------------------- */
+int  rr_create(int device_ordinal, rr_context** out);
+int  rr_destroy(rr_context* ctx);
+const char* rr_last_error(const rr_context* ctx);
+/* Use a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own;
+ * NULL restores the context's stream.  Stands where the command queue of :161-166 stood. */
+int  rr_set_stream(rr_context* ctx, void* hip_stream);
+/* wait_until_finished, RefractionDemo.cpp:65-71 */
+int  rr_wait(rr_context* ctx);
+
+/* ---- assets -> device -------------------------------------------------------------------- */
+/* Mesh::upload, Mesh.cpp:55-94 (+ geometry desc Mesh.cpp:39-53): copies; caller keeps ownership. */
+int  rr_upload_mesh(rr_context* ctx, const rr_vertex* verts, uint32_t n_verts,
+                    const uint32_t* indices, uint32_t n_indices, uint32_t* mesh_id);
+/* load_texture, RefractionDemo.cpp:108-140: tightly packed RGB32F, row pitch w*12 (:128). */
+int  rr_upload_envmap(rr_context* ctx, const float* rgb, int32_t w, int32_t h);
+
+/* ---- acceleration structures: RefractionDemo.cpp:272-361 ----------------------------------- */
+/* BuildRaytracingAccelerationStructure (bottom level), :277-322 */
+int  rr_build_blas(rr_context* ctx, uint32_t mesh_id);
+/* BuildRaytracingAccelerationStructure (top level), :324-356.  n == 0 is invalid; the
+ * reference's scene is one identity instance with mask 1 and flags 0. */
+int  rr_build_tlas(rr_context* ctx, const rr_instance_desc* instances, uint32_t n);
+
+/* ---- per frame ----------------------------------------------------------------------------- */
+/* copy_to_buffer(cameraConstantBuffer, ...), RefractionDemo.cpp:566 */
+int  rr_set_camera(rr_context* ctx, const rr_scene_constants* constants);
+/* Multi-GPU sharding (new; the reference is single-adapter): this context renders only the
+ * 32x32-pixel tiles t with t % world == rank.  world == 1 (default) renders the whole frame. */
+int  rr_set_tile_partition(rr_context* ctx, uint32_t rank, uint32_t world);
+/* DispatchRays(desc{W,H,1}), RefractionDemo.cpp:580-594.  Asynchronous on the stream. */
+int  rr_dispatch_rays(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispatch_params* params);
+/* CopyResource(backbuffer <- rtTexture) + Present, RefractionDemo.cpp:596-609: blocks, copies the
+ * R8G8B8A8_UNORM frame (and the float4 frame if RR_DISPATCH_FLOAT_OUTPUT was set) to host memory.
+ * Either pointer may be NULL.  Only valid with world == 1. */
+int  rr_read_frame(rr_context* ctx, uint8_t* rgba8, float* rgba32f);
+
+/* Sharded output.  A context with world > 1 renders into a compact tile buffer:
+ * rr_local_tile_count tiles of 32*32 RGBA8 pixels (4096 B each), tile-major. */
+int  rr_local_tile_count(rr_context* ctx, uint32_t width, uint32_t height, uint32_t* n_tiles,
+                         uint32_t* max_tiles_any_rank);
+/* device -> device copy of this rank's tiles into caller memory (e.g. a torch tensor that RCCL
+ * will gather); dst must hold max_tiles_any_rank*4096 bytes, the tail is zero-filled. */
+int  rr_export_tiles(rr_context* ctx, void* d_dst);
+/* rank 0: de-interleave the gathered [world][max_tiles][4096 B] buffer into a W*H RGBA8 frame.
+ * d_frame may be NULL (an internal frame is used; fetch it with rr_read_frame). */
+int  rr_assemble_tiles(rr_context* ctx, const void* d_gathered, uint32_t world, void* d_frame);
+
+/* exact counters of the last dispatch (blocks until it finished) */
+int  rr_get_stats(rr_context* ctx, rr_stats* out);
+
+/* TraceRay on caller-supplied rays (host arrays), same traversal code as the render path.
+ * Stands for RayTracing.hlsl:60,106,121 in isolation; used by the parity tests. */
+int  rr_trace_rays(rr_context* ctx, const rr_ray* rays, uint32_t n, rr_hit* hits);
+
+/* Introspection for tests: copies the packed BLAS of a mesh to host.  nodes: n_nodes*64 B
+ * (two child boxes + two child refs), tris: n_tris*48 B (v0,e1,e2 with prim id in v0.w). */
+int  rr_download_blas(rr_context* ctx, uint32_t mesh_id, void* nodes, uint32_t* n_nodes,
+                      void* tris, uint32_t* n_tris);
+
+/* ---- pure host helpers (no device, no context) --------------------------------------------- */
+void rr_default_dispatch_params(rr_dispatch_params* p);
+/* RefractionDemo.cpp:559-566: camera constants for an orbit angle.  The reference's literals are
+ * fov_y = float(52.0/180.0*3.1415), aspect = 1.333f, zn = 1, zf = 125; frame k uses angle 0.01*(k+1). */
+int  rr_host_camera_orbit(float angle, float fov_y, float aspect, float zn, float zf,
+                          rr_scene_constants* out);
+/* Mesh::load, Mesh.cpp:6-37.  Arrays are malloc'ed, release with rr_host_free.  A file that cannot
+ * be opened returns RR_ERR_IO (Mesh::load returns false). */
+int  rr_host_mesh_load_obj(const char* filename, rr_vertex** verts, uint32_t* n_verts,
+                           uint32_t** indices, uint32_t* n_indices);
+/* stbi_loadf(file,&x,&y,&n,req_comp) as called at RefractionDemo.cpp:111: Radiance .hdr and .png
+ * (8/16-bit, non-interlaced), LDR expanded with pow(v/255, 2.2).  NULL on failure. */
+float* rr_host_image_loadf(const char* filename, int* x, int* y, int* channels_in_file, int req_comp);
+/* Radiance RLE .hdr writer (the reference's envmap.hdr is missing from the mount). */
+int  rr_host_image_write_hdr(const char* filename, int w, int h, const float* rgb);
+void rr_host_free(void* p);
+uint32_t rr_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RRDXR_H */

@@ -1,0 +1,83 @@
+// RefractionDemo.cpp -- the reference's frame driver (RefractionDemo.cpp:513-612) over the rrdxr
+// C ABI.  Same call order as the reference's initialize(): device, env map, mesh load + upload,
+// acceleration structures, then per frame: camera constants, DispatchRays, copy out, wait.
+#include "RefractionDemo.hpp"
+
+#include <cstring>
+
+namespace RefractionDemo {
+namespace {
+rr_context* g_ctx = nullptr;
+Mesh cubeMesh;                               // the reference's name for its one mesh (RefractionDemo.cpp:17)
+Options g_opt;
+float g_angle = 0.01f;                       // static float angle (RefractionDemo.cpp:555)
+std::vector<uint8_t> g_back;
+std::string g_err;
+
+int fail(int code, const char* what)
+{
+    g_err = what;
+    if (g_ctx && code != RR_ERR_IO) { g_err += ": "; g_err += rr_last_error(g_ctx); }
+    return code;
+}
+} // namespace
+
+int initialize(const Options& opt)
+{
+    shutdown();
+    g_opt = opt;
+    g_angle = opt.angle0;
+    int rc = rr_create(opt.device, &g_ctx);                               // createDevice :142-172
+    if (rc != RR_OK) return fail(rc, "rr_create");
+
+    int x = 0, y = 0, n = 0;                                              // load_texture :108-140
+    float* env = rr_host_image_loadf(opt.env_path.c_str(), &x, &y, &n, 3);
+    if (!env) return fail(RR_ERR_IO, "env map could not be loaded");      // the reference does not check (:111)
+    rc = rr_upload_envmap(g_ctx, env, x, y);
+    rr_host_free(env);
+    if (rc != RR_OK) return fail(rc, "rr_upload_envmap");
+
+    cubeMesh = Mesh();
+    if (!cubeMesh.load(opt.mesh_path.c_str())) return fail(RR_ERR_IO, "mesh could not be loaded");   // :537
+    if ((rc = cubeMesh.upload(g_ctx)) != RR_OK) return fail(rc, "Mesh::upload");                      // :538
+
+    // setupRaytracingAccelerationStructures :272-361: one BLAS, one identity instance, mask 1, flags 0
+    const RaytracingGeometry geo = cubeMesh.raytracingGeometry();
+    if ((rc = rr_build_blas(g_ctx, geo.mesh_id)) != RR_OK) return fail(rc, "rr_build_blas");
+    rr_instance_desc inst;
+    std::memset(&inst, 0, sizeof inst);
+    inst.transform[0] = inst.transform[5] = inst.transform[10] = 1.0f;    // :325-327
+    inst.instance_id_mask = 1u << 24;                                     // InstanceMask = 1, InstanceID = 0
+    inst.hitgroup_flags = 0;
+    inst.blas = geo.mesh_id;
+    if ((rc = rr_build_tlas(g_ctx, &inst, 1)) != RR_OK) return fail(rc, "rr_build_tlas");
+
+    g_back.assign((size_t)opt.width * opt.height * 4, 0);
+    return RR_OK;
+}
+
+int drawFrame()
+{
+    if (!g_ctx) return fail(RR_ERR_STATE, "initialize first");
+    rr_scene_constants sc;
+    int rc = rr_host_camera_orbit(g_angle, g_opt.fov_y, g_opt.aspect, g_opt.zn, g_opt.zf, &sc);      // :559-565
+    if (rc != RR_OK) return fail(rc, "rr_host_camera_orbit");
+    if ((rc = rr_set_camera(g_ctx, &sc)) != RR_OK) return fail(rc, "rr_set_camera");                  // :566
+    g_angle += g_opt.angle_step;                                                                      // :567
+    if ((rc = rr_dispatch_rays(g_ctx, (uint32_t)g_opt.width, (uint32_t)g_opt.height, &g_opt.dispatch)) != RR_OK)
+        return fail(rc, "rr_dispatch_rays");                                                          // :580-594
+    if ((rc = rr_read_frame(g_ctx, g_back.data(), nullptr)) != RR_OK) return fail(rc, "rr_read_frame");   // :596-611
+    return RR_OK;
+}
+
+const std::vector<uint8_t>& backBuffer() { return g_back; }
+rr_context* context() { return g_ctx; }
+float currentAngle() { return g_angle; }
+const char* lastError() { return g_err.c_str(); }
+
+void shutdown()
+{
+    if (g_ctx) { rr_destroy(g_ctx); g_ctx = nullptr; }
+}
+
+} // namespace RefractionDemo

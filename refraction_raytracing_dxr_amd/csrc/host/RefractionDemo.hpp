@@ -1,0 +1,37 @@
+// RefractionDemo.hpp -- headless mirror of the reference's host API (RefractionDemo.hpp:9-10):
+//   void initialize(HWND, int width, int height)   ->  int initialize(const Options&)
+//   void drawFrame()                               ->  int drawFrame()
+// The window handle is gone (no swap chain); the literals of RefractionDemo.cpp become Options
+// whose defaults are those literals.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "Mesh.hpp"
+
+namespace RefractionDemo {
+
+struct Options {
+    int width = 1024, height = 768;                       // WinMain.cpp:44
+    std::string mesh_path = "../shell.obj";               // RefractionDemo.cpp:537
+    std::string env_path = "../envMap.hdr";               // RefractionDemo.cpp:527
+    int device = 0;
+    float fov_y = (float)(52.0f / 180.0 * 3.1415);        // RefractionDemo.cpp:559
+    float aspect = (float)1.333;
+    float zn = 1.0f, zf = 125.0f;
+    float angle0 = 0.01f, angle_step = 0.01f;             // RefractionDemo.cpp:555,567
+    rr_dispatch_params dispatch;                          // RayTracing.hlsl literals
+    Options() { rr_default_dispatch_params(&dispatch); }
+};
+
+int initialize(const Options& opt);       // RefractionDemo.cpp:513-553; returns rr_status
+int drawFrame();                          // RefractionDemo.cpp:557-612; returns rr_status
+// the frame drawFrame just produced (RGBA8, width*height*4), i.e. what Present would have shown
+const std::vector<uint8_t>& backBuffer();
+rr_context* context();
+float currentAngle();
+const char* lastError();
+void shutdown();
+
+} // namespace RefractionDemo

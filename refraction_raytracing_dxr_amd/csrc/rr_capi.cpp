@@ -1,0 +1,648 @@
+// rr_capi.cpp -- the C ABI of include/rrdxr.h over HIP streams.
+//
+// Stands where RefractionDemo.cpp's D3D12 plumbing stood: createDevice (:142-172), Mesh::upload
+// (Mesh.cpp:55-94), load_texture (:108-140), the two BuildRaytracingAccelerationStructure calls
+// (:277-356), the per-frame constant-buffer copy (:566), DispatchRays (:580-594), the UAV ->
+// backbuffer copy (:596-604) and the fence wait (:65-71).  Everything device-side is a kernel in
+// rr_bvh_build.hip / rr_render.hip; this file only owns memory, call order and error reporting.
+#include "../../include/rrdxr.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rr_launch.h"
+
+using namespace rr;
+
+static_assert(sizeof(rr_vertex) == 32, "Vertex stride (Mesh.cpp:45)");
+static_assert(sizeof(rr_instance_desc) == 64, "D3D12_RAYTRACING_INSTANCE_DESC");
+static_assert(sizeof(rr_scene_constants) == 80, "SceneConstants");
+static_assert(sizeof(rr_ray) == sizeof(rr_ray_dev) && sizeof(rr_hit) == sizeof(rr_hit_dev), "ray/hit ABI");
+
+namespace {
+
+struct MeshRes {
+    float*    d_verts = nullptr;     // n_verts * 8 floats
+    uint32_t* d_idx = nullptr;
+    uint32_t  n_verts = 0, n_idx = 0, n_tris = 0;
+    BvhNode*  nodes = nullptr;
+    TriRec*   tris = nullptr;
+    NrmRec*   nrms = nullptr;
+    bool      built = false;
+    float     bounds[6] = { 0, 0, 0, 0, 0, 0 };
+    uint32_t  depth = 0;
+};
+
+// device block zeroed before every dispatch: counters, ray shards, error flag
+struct CounterBlock {
+    unsigned long long counters[16];
+    uint32_t shards[RAY_SHARDS];
+    uint32_t error;
+    uint32_t pad[3];
+};
+
+} // namespace
+
+struct rr_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    std::vector<MeshRes> meshes;
+
+    float4* d_env = nullptr;
+    int env_w = 0, env_h = 0;
+
+    // TLAS
+    std::vector<rr_instance_desc> inst_host;
+    InstDev* d_insts = nullptr;
+    BvhNode* d_tlas = nullptr;
+    uint32_t n_insts = 0, tlas_depth = 0;
+    bool tlas_built = false;
+    bool single_identity = false;
+
+    rr_scene_constants cam;
+    bool cam_set = false;
+    uint32_t tile_rank = 0, tile_world = 1;
+
+    // frame
+    uint32_t W = 0, H = 0, frame_world = 0;
+    uint32_t* d_rgba8 = nullptr;     // world==1: W*H; else local tiles
+    float4*   d_f32 = nullptr;
+    uint32_t* d_assembled = nullptr; // rank-0 raster after rr_assemble_tiles
+    size_t    rgba_elems = 0, f32_elems = 0, assembled_elems = 0;
+    bool      have_f32 = false, have_frame = false, have_assembled = false;
+    uint32_t  last_pixels = 0;
+    bool      last_stats = false;
+
+    CounterBlock* d_cnt = nullptr;
+
+    // trace_rays scratch
+    rr_ray_dev* d_rays = nullptr;
+    rr_hit_dev* d_hits = nullptr;
+    uint32_t ray_cap = 0;
+};
+
+namespace {
+
+int fail(rr_context* ctx, int code, const char* what, hipError_t e = hipSuccess)
+{
+    if (ctx) {
+        ctx->err = what;
+        if (e != hipSuccess) { ctx->err += ": "; ctx->err += hipGetErrorString(e); }
+    }
+    return code;
+}
+
+#define RR_HIP(call)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess) return fail(ctx, e_ == hipErrorOutOfMemory ? RR_ERR_OUT_OF_MEMORY : RR_ERR_DEVICE, #call, e_); \
+    } while (0)
+
+template <class T> void dfree(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+uint32_t next_pow2(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
+
+// world -> object inverse of a 3x4 affine (adjugate / det, fixed operation order; mirrored by the oracle)
+void affine_inverse(const float t[12], float inv[12])
+{
+    float a = t[0], b = t[1], c = t[2], d = t[4], e = t[5], f = t[6], g = t[8], h = t[9], i = t[10];
+    float c00 = e * i - f * h, c01 = f * g - d * i, c02 = d * h - e * g;
+    float det = (a * c00 + b * c01) + c * c02;
+    float r = 1.0f / det;
+    inv[0] = c00 * r; inv[1] = (c * h - b * i) * r; inv[2] = (b * f - c * e) * r;
+    inv[4] = c01 * r; inv[5] = (a * i - c * g) * r; inv[6] = (c * d - a * f) * r;
+    inv[8] = c02 * r; inv[9] = (b * g - a * h) * r; inv[10] = (a * e - b * d) * r;
+    float tx = t[3], ty = t[7], tz = t[11];
+    inv[3] = -((inv[0] * tx + inv[1] * ty) + inv[2] * tz);
+    inv[7] = -((inv[4] * tx + inv[5] * ty) + inv[6] * tz);
+    inv[11] = -((inv[8] * tx + inv[9] * ty) + inv[10] * tz);
+}
+
+float ord2f_host(uint32_t u)
+{
+    uint32_t v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f;
+    memcpy(&f, &v, 4);
+    return f;
+}
+
+struct BuildScratch {
+    BuildBuffers b{};
+    void* raw = nullptr;
+    ~BuildScratch() { if (raw) (void)hipFree(raw); }
+};
+
+// one allocation carved into the builder's scratch arrays (16-byte aligned pieces)
+int alloc_build(rr_context* ctx, uint32_t n, BuildScratch& s)
+{
+    const uint32_t n_pad = next_pow2(n);
+    auto al = [](size_t v) { return (v + 255u) & ~(size_t)255u; };
+    size_t o_box = 0;
+    size_t o_keys = o_box + al((size_t)n * 6 * 4);
+    size_t o_parent = o_keys + al((size_t)n_pad * 8);
+    size_t o_child = o_parent + al((size_t)(2 * (size_t)n) * 4);
+    size_t o_nbox = o_child + al((size_t)(2 * (size_t)n) * 4);
+    size_t o_visit = o_nbox + al((size_t)(2 * (size_t)n) * 6 * 4);
+    size_t o_scene = o_visit + al((size_t)n * 4);
+    size_t o_depth = o_scene + al(6 * 4);
+    size_t total = o_depth + al(4);
+    RR_HIP(hipMalloc(&s.raw, total));
+    char* base = (char*)s.raw;
+    s.b.n = n; s.b.n_pad = n_pad;
+    s.b.prim_box = (float*)(base + o_box);
+    s.b.keys = (unsigned long long*)(base + o_keys);
+    s.b.parent = (int32_t*)(base + o_parent);
+    s.b.child = (int32_t*)(base + o_child);
+    s.b.node_box = (float*)(base + o_nbox);
+    s.b.visit = (uint32_t*)(base + o_visit);
+    s.b.scene_box = (uint32_t*)(base + o_scene);
+    s.b.depth = (uint32_t*)(base + o_depth);
+    return RR_OK;
+}
+
+int use_device(rr_context* ctx)
+{
+    if (!ctx) return RR_ERR_INVALID_ARGUMENT;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, RR_ERR_DEVICE, "hipSetDevice", e);
+    return RR_OK;
+}
+
+void fill_scene(const rr_context* ctx, SceneDev& sc)
+{
+    memset(&sc, 0, sizeof sc);
+    const MeshRes* m0 = nullptr;
+    if (ctx->single_identity) m0 = &ctx->meshes[(size_t)ctx->inst_host[0].blas];
+    if (m0) {
+        sc.blas0.nodes = m0->nodes; sc.blas0.tris = m0->tris; sc.blas0.nrms = m0->nrms;
+        sc.blas0.n_tris = m0->n_tris; sc.blas0.depth = m0->depth;
+    }
+    sc.tlas_nodes = ctx->d_tlas;
+    sc.insts = ctx->d_insts;
+    sc.n_insts = ctx->n_insts;
+    sc.single_identity = ctx->single_identity ? 1u : 0u;
+    sc.env = ctx->d_env;
+    sc.env_w = ctx->env_w; sc.env_h = ctx->env_h;
+}
+
+// deepest traversal stack the scene can need (near child followed, far child pushed)
+uint32_t scene_stack_need(const rr_context* ctx)
+{
+    uint32_t blas_max = 0;
+    for (uint32_t i = 0; i < ctx->n_insts; ++i) {
+        const MeshRes& m = ctx->meshes[(size_t)ctx->inst_host[i].blas];
+        if (m.depth > blas_max) blas_max = m.depth;
+    }
+    return ctx->single_identity ? blas_max : blas_max + ctx->tlas_depth;
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t rr_abi_version(void) { return RRDXR_ABI_VERSION; }
+
+void rr_default_dispatch_params(rr_dispatch_params* p)
+{
+    if (!p) return;
+    p->max_refract = 5;
+    p->max_reflect = 2;
+    p->ior = 1.3f;
+    p->tmin_primary = 0.0001f;
+    p->tmax_primary = 100.0f;
+    p->tmin_secondary = 0.001f;
+    p->tmax_secondary = 1000.0f;
+    p->flags = 0;
+}
+
+int rr_create(int device_ordinal, rr_context** out)
+{
+    if (!out) return RR_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RR_ERR_NO_DEVICE;
+    if (device_ordinal < 0 || device_ordinal >= n) return RR_ERR_INVALID_ARGUMENT;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) return RR_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return RR_ERR_NO_DEVICE;   // the code object is gfx950 only
+    rr_context* ctx = new (std::nothrow) rr_context();
+    if (!ctx) return RR_ERR_OUT_OF_MEMORY;
+    ctx->device = device_ordinal;
+    if (hipSetDevice(device_ordinal) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(&ctx->d_cnt, sizeof(CounterBlock)) != hipSuccess) {
+        if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+        delete ctx;
+        return RR_ERR_DEVICE;
+    }
+    ctx->stream = ctx->own_stream;
+    (void)hipMemsetAsync(ctx->d_cnt, 0, sizeof(CounterBlock), ctx->stream);
+    *out = ctx;
+    return RR_OK;
+}
+
+int rr_destroy(rr_context* ctx)
+{
+    if (!ctx) return RR_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (MeshRes& m : ctx->meshes) { dfree(m.d_verts); dfree(m.d_idx); dfree(m.nodes); dfree(m.tris); dfree(m.nrms); }
+    dfree(ctx->d_env); dfree(ctx->d_insts); dfree(ctx->d_tlas); dfree(ctx->d_rgba8); dfree(ctx->d_f32);
+    dfree(ctx->d_assembled); dfree(ctx->d_cnt); dfree(ctx->d_rays); dfree(ctx->d_hits);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return RR_OK;
+}
+
+const char* rr_last_error(const rr_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int rr_set_stream(rr_context* ctx, void* hip_stream)
+{
+    if (int r = use_device(ctx)) return r;
+    RR_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return RR_OK;
+}
+
+int rr_wait(rr_context* ctx)
+{
+    if (int r = use_device(ctx)) return r;
+    RR_HIP(hipStreamSynchronize(ctx->stream));
+    return RR_OK;
+}
+
+int rr_upload_mesh(rr_context* ctx, const rr_vertex* verts, uint32_t n_verts, const uint32_t* indices, uint32_t n_indices,
+                   uint32_t* mesh_id)
+{
+    if (int r = use_device(ctx)) return r;
+    if (!verts || !indices || !mesh_id || n_verts == 0 || n_indices < 3 || n_indices % 3 != 0)
+        return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_upload_mesh: need >= 1 triangle, n_indices % 3 == 0");
+    for (uint32_t i = 0; i < n_indices; ++i)
+        if (indices[i] >= n_verts) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_upload_mesh: index out of range");
+    MeshRes m;
+    m.n_verts = n_verts; m.n_idx = n_indices; m.n_tris = n_indices / 3;
+    RR_HIP(hipMalloc(&m.d_verts, (size_t)n_verts * sizeof(rr_vertex)));
+    hipError_t e = hipMalloc(&m.d_idx, (size_t)n_indices * 4);
+    if (e != hipSuccess) { dfree(m.d_verts); return fail(ctx, RR_ERR_OUT_OF_MEMORY, "hipMalloc(indices)", e); }
+    // Mesh.cpp:76-79,88-91: memcpy into the mapped upload buffers
+    e = hipMemcpyAsync(m.d_verts, verts, (size_t)n_verts * sizeof(rr_vertex), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(m.d_idx, indices, (size_t)n_indices * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // caller keeps ownership of the host arrays
+    if (e != hipSuccess) { dfree(m.d_verts); dfree(m.d_idx); return fail(ctx, RR_ERR_DEVICE, "mesh upload", e); }
+    ctx->meshes.push_back(m);
+    *mesh_id = (uint32_t)ctx->meshes.size() - 1u;
+    return RR_OK;
+}
+
+int rr_upload_envmap(rr_context* ctx, const float* rgb, int32_t w, int32_t h)
+{
+    if (int r = use_device(ctx)) return r;
+    if (!rgb || w <= 0 || h <= 0) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_upload_envmap: null data or empty size");
+    const size_t n = (size_t)w * (size_t)h;
+    float* staging = nullptr;
+    float4* env = nullptr;
+    RR_HIP(hipMalloc(&staging, n * 12));
+    hipError_t e = hipMalloc(&env, n * 16);
+    if (e == hipSuccess) e = hipMemcpyAsync(staging, rgb, n * 12, hipMemcpyHostToDevice, ctx->stream);   // RowPitch = x*3*4 (:128)
+    if (e == hipSuccess) e = launch_env_pad(staging, env, (uint32_t)n, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(staging);
+    if (e != hipSuccess) { if (env) (void)hipFree(env); return fail(ctx, RR_ERR_DEVICE, "env upload", e); }
+    dfree(ctx->d_env);
+    ctx->d_env = env; ctx->env_w = w; ctx->env_h = h;
+    return RR_OK;
+}
+
+int rr_build_blas(rr_context* ctx, uint32_t mesh_id)
+{
+    if (int r = use_device(ctx)) return r;
+    if (mesh_id >= ctx->meshes.size()) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_build_blas: unknown mesh id");
+    MeshRes& m = ctx->meshes[mesh_id];
+    const uint32_t n = m.n_tris;
+    BuildScratch s;
+    if (int r = alloc_build(ctx, n, s)) return r;
+    dfree(m.nodes); dfree(m.tris); dfree(m.nrms);
+    m.built = false;
+    RR_HIP(hipMalloc(&m.nodes, (size_t)(n > 1 ? n - 1 : 1) * sizeof(BvhNode)));
+    RR_HIP(hipMalloc(&m.tris, (size_t)n * sizeof(TriRec)));
+    RR_HIP(hipMalloc(&m.nrms, (size_t)n * sizeof(NrmRec)));
+    s.b.nodes = m.nodes;
+    RR_HIP(launch_tri_setup(m.d_verts, m.d_idx, n, s.b, ctx->stream));
+    RR_HIP(launch_lbvh(s.b, ctx->stream));
+    RR_HIP(launch_pack_tris(m.d_verts, m.d_idx, s.b, m.tris, m.nrms, ctx->stream));
+    uint32_t sb[6], depth = 0;
+    RR_HIP(hipMemcpyAsync(sb, s.b.scene_box, sizeof sb, hipMemcpyDeviceToHost, ctx->stream));
+    RR_HIP(hipMemcpyAsync(&depth, s.b.depth, 4, hipMemcpyDeviceToHost, ctx->stream));
+    RR_HIP(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 6; ++k) m.bounds[k] = ord2f_host(sb[k]);
+    m.depth = depth;
+    if (depth > 64) return fail(ctx, RR_ERR_UNSUPPORTED, "rr_build_blas: LBVH deeper than the 64-entry traversal stack");
+    m.built = true;
+    ctx->tlas_built = false;      // any TLAS built before refers to the old BLAS
+    return RR_OK;
+}
+
+int rr_build_tlas(rr_context* ctx, const rr_instance_desc* instances, uint32_t n)
+{
+    if (int r = use_device(ctx)) return r;
+    if (!instances || n == 0) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_build_tlas: need >= 1 instance");
+    for (uint32_t i = 0; i < n; ++i) {
+        if (instances[i].blas >= ctx->meshes.size()) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_build_tlas: unknown BLAS");
+        if (!ctx->meshes[(size_t)instances[i].blas].built) return fail(ctx, RR_ERR_STATE, "rr_build_tlas: BLAS not built");
+    }
+    static const float ident[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
+    std::vector<InstDev> host(n);
+    std::vector<float> xb((size_t)n * 18);
+    for (uint32_t i = 0; i < n; ++i) {
+        const rr_instance_desc& d = instances[i];
+        const MeshRes& m = ctx->meshes[(size_t)d.blas];
+        InstDev& o = host[i];
+        memset(&o, 0, sizeof o);
+        o.identity = memcmp(d.transform, ident, sizeof ident) == 0 ? 1u : 0u;
+        if (o.identity) memcpy(o.inv, ident, sizeof ident);
+        else {
+            affine_inverse(d.transform, o.inv);
+            for (int k = 0; k < 12; ++k)
+                if (!std::isfinite(o.inv[k])) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_build_tlas: singular instance transform");
+        }
+        o.blas.nodes = m.nodes; o.blas.tris = m.tris; o.blas.nrms = m.nrms; o.blas.n_tris = m.n_tris; o.blas.depth = m.depth;
+        o.flags = d.hitgroup_flags >> 24;
+        o.mask = d.instance_id_mask >> 24;
+        memcpy(&xb[(size_t)i * 12], d.transform, 48);
+        memcpy(&xb[(size_t)n * 12 + (size_t)i * 6], m.bounds, 24);
+    }
+    ctx->tlas_built = false;
+    dfree(ctx->d_insts); dfree(ctx->d_tlas);
+    RR_HIP(hipMalloc(&ctx->d_insts, (size_t)n * sizeof(InstDev)));
+    RR_HIP(hipMalloc(&ctx->d_tlas, (size_t)(n > 1 ? n - 1 : 1) * sizeof(BvhNode)));
+    float* d_xb = nullptr;
+    RR_HIP(hipMalloc(&d_xb, xb.size() * 4));
+    BuildScratch s;
+    int rc = alloc_build(ctx, n, s);
+    hipError_t e = hipSuccess;
+    uint32_t depth = 0;
+    if (rc == RR_OK) {
+        s.b.nodes = ctx->d_tlas;
+        s.b.leaf_ref_prim = 1;
+        e = hipMemcpyAsync(ctx->d_insts, host.data(), (size_t)n * sizeof(InstDev), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_xb, xb.data(), xb.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = launch_inst_setup(ctx->d_insts, d_xb, n, s.b, ctx->stream);
+        if (e == hipSuccess) e = launch_lbvh(s.b, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&depth, s.b.depth, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    (void)hipFree(d_xb);
+    if (rc != RR_OK) return rc;
+    if (e != hipSuccess) return fail(ctx, RR_ERR_DEVICE, "TLAS build", e);
+    ctx->inst_host.assign(instances, instances + n);
+    ctx->n_insts = n;
+    ctx->tlas_depth = depth;
+    const rr_instance_desc& d0 = instances[0];
+    ctx->single_identity = n == 1 && host[0].identity && (d0.hitgroup_flags >> 24) == 0 && ((d0.instance_id_mask >> 24) & 0xffu) != 0;
+    if (scene_stack_need(ctx) > 64) return fail(ctx, RR_ERR_UNSUPPORTED, "rr_build_tlas: TLAS+BLAS deeper than the 64-entry stack");
+    ctx->tlas_built = true;
+    return RR_OK;
+}
+
+int rr_set_camera(rr_context* ctx, const rr_scene_constants* constants)
+{
+    if (!ctx || !constants) return RR_ERR_INVALID_ARGUMENT;
+    ctx->cam = *constants;
+    ctx->cam_set = true;
+    return RR_OK;
+}
+
+int rr_set_tile_partition(rr_context* ctx, uint32_t rank, uint32_t world)
+{
+    if (!ctx) return RR_ERR_INVALID_ARGUMENT;
+    if (world == 0 || rank >= world) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_set_tile_partition: need rank < world");
+    ctx->tile_rank = rank; ctx->tile_world = world;
+    return RR_OK;
+}
+
+static void tile_counts(uint32_t W, uint32_t H, uint32_t rank, uint32_t world, uint32_t& tiles_x, uint32_t& n_tiles,
+                        uint32_t& local, uint32_t& max_local)
+{
+    tiles_x = (W + TILE - 1) / TILE;
+    n_tiles = tiles_x * ((H + TILE - 1) / TILE);
+    local = n_tiles > rank ? (n_tiles - rank + world - 1) / world : 0;
+    max_local = (n_tiles + world - 1) / world;
+}
+
+int rr_local_tile_count(rr_context* ctx, uint32_t width, uint32_t height, uint32_t* n_tiles, uint32_t* max_tiles_any_rank)
+{
+    if (!ctx || width == 0 || height == 0) return RR_ERR_INVALID_ARGUMENT;
+    uint32_t tx, nt, local, mx;
+    tile_counts(width, height, ctx->tile_rank, ctx->tile_world, tx, nt, local, mx);
+    if (n_tiles) *n_tiles = local;
+    if (max_tiles_any_rank) *max_tiles_any_rank = mx;
+    return RR_OK;
+}
+
+int rr_dispatch_rays(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispatch_params* params)
+{
+    if (int r = use_device(ctx)) return r;
+    if (width == 0 || height == 0 || width > 32768 || height > 32768)
+        return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_dispatch_rays: bad frame size");
+    if (!ctx->tlas_built) return fail(ctx, RR_ERR_STATE, "rr_dispatch_rays: build the BLAS and TLAS first");
+    if (!ctx->cam_set) return fail(ctx, RR_ERR_STATE, "rr_dispatch_rays: rr_set_camera first");
+    rr_dispatch_params p;
+    if (params) p = *params; else rr_default_dispatch_params(&p);
+    if (p.max_refract < 0 || p.max_refract > 65535 || p.max_reflect < 0)
+        return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_dispatch_rays: negative bounce limit");
+    if (p.max_reflect > 8) return fail(ctx, RR_ERR_UNSUPPORTED, "rr_dispatch_rays: max_reflect > 8 (parked-ray registers)");
+    if (!(p.ior > 0.0f)) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_dispatch_rays: ior must be > 0");
+
+    uint32_t tiles_x, n_tiles, local, max_local;
+    tile_counts(width, height, ctx->tile_rank, ctx->tile_world, tiles_x, n_tiles, local, max_local);
+    const bool want_f32 = (p.flags & RR_DISPATCH_FLOAT_OUTPUT) != 0;
+    const size_t elems = ctx->tile_world == 1 ? (size_t)width * height : (size_t)max_local * TILE * TILE;
+    if (elems > ctx->rgba_elems || !ctx->d_rgba8) {
+        RR_HIP(hipStreamSynchronize(ctx->stream));
+        dfree(ctx->d_rgba8);
+        ctx->rgba_elems = 0;
+        RR_HIP(hipMalloc(&ctx->d_rgba8, elems * 4));
+        ctx->rgba_elems = elems;
+    }
+    if (want_f32 && (elems > ctx->f32_elems || !ctx->d_f32)) {
+        RR_HIP(hipStreamSynchronize(ctx->stream));
+        dfree(ctx->d_f32);
+        ctx->f32_elems = 0;
+        RR_HIP(hipMalloc(&ctx->d_f32, elems * 16));
+        ctx->f32_elems = elems;
+    }
+
+    SceneDev sc;
+    fill_scene(ctx, sc);
+    DispatchDev a;
+    memset(&a, 0, sizeof a);
+    memcpy(a.M, ctx->cam.proj_inv, 64);
+    memcpy(a.cam, ctx->cam.camera_loc, 16);
+    a.W = width; a.H = height; a.tiles_x = tiles_x; a.n_tiles = n_tiles;
+    a.tile_rank = ctx->tile_rank; a.tile_world = ctx->tile_world;
+    a.n_blocks = local * 4u;
+    a.max_refract = p.max_refract; a.max_reflect = p.max_reflect;
+    a.ior = p.ior; a.inv_ior = 1.0f / p.ior;
+    a.tmin_p = p.tmin_primary; a.tmax_p = p.tmax_primary; a.tmin_s = p.tmin_secondary; a.tmax_s = p.tmax_secondary;
+    a.out_rgba8 = ctx->d_rgba8;
+    a.out_f32 = want_f32 ? ctx->d_f32 : nullptr;
+    a.counters = ctx->d_cnt->counters;
+    a.ray_shards = ctx->d_cnt->shards;
+    a.error_flag = &ctx->d_cnt->error;
+
+    const bool stats = (p.flags & RR_DISPATCH_COLLECT_STATS) != 0;
+    const uint32_t need = scene_stack_need(ctx);
+    RR_HIP(hipMemsetAsync(ctx->d_cnt, 0, sizeof(CounterBlock), ctx->stream));
+    if (ctx->tile_world > 1 && local < max_local)   // keep the gathered tail deterministic
+        RR_HIP(hipMemsetAsync(ctx->d_rgba8 + (size_t)local * TILE * TILE, 0, (size_t)(max_local - local) * TILE * TILE * 4, ctx->stream));
+    RR_HIP(launch_render_fused(sc, a, need <= 32 ? 32 : 64, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream));
+    ctx->W = width; ctx->H = height; ctx->frame_world = ctx->tile_world;
+    ctx->have_f32 = want_f32; ctx->have_frame = true; ctx->have_assembled = false;
+    ctx->last_stats = stats;
+    // pixels actually owned by this rank (partial edge tiles counted exactly)
+    uint64_t px = 0;
+    for (uint32_t t = ctx->tile_rank; t < n_tiles; t += ctx->tile_world) {
+        uint32_t x0 = (t % tiles_x) * TILE, y0 = (t / tiles_x) * TILE;
+        uint32_t w = width - x0 < TILE ? width - x0 : TILE, h = height - y0 < TILE ? height - y0 : TILE;
+        px += (uint64_t)w * h;
+    }
+    ctx->last_pixels = (uint32_t)px;
+    return RR_OK;
+}
+
+int rr_read_frame(rr_context* ctx, uint8_t* rgba8, float* rgba32f)
+{
+    if (int r = use_device(ctx)) return r;
+    if (!ctx->have_frame) return fail(ctx, RR_ERR_STATE, "rr_read_frame: nothing dispatched");
+    const size_t n = (size_t)ctx->W * ctx->H;
+    if (ctx->have_assembled) {
+        if (rgba32f) return fail(ctx, RR_ERR_STATE, "rr_read_frame: float output is not gathered across ranks");
+        if (rgba8) RR_HIP(hipMemcpyAsync(rgba8, ctx->d_assembled, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        if (ctx->frame_world != 1) return fail(ctx, RR_ERR_STATE, "rr_read_frame: sharded frame, gather + rr_assemble_tiles first");
+        if (rgba32f && !ctx->have_f32) return fail(ctx, RR_ERR_STATE, "rr_read_frame: dispatch with RR_DISPATCH_FLOAT_OUTPUT");
+        if (rgba8) RR_HIP(hipMemcpyAsync(rgba8, ctx->d_rgba8, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (rgba32f) RR_HIP(hipMemcpyAsync(rgba32f, ctx->d_f32, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    RR_HIP(hipStreamSynchronize(ctx->stream));
+    uint32_t err = 0;
+    RR_HIP(hipMemcpy(&err, &ctx->d_cnt->error, 4, hipMemcpyDeviceToHost));
+    if (err) return fail(ctx, RR_ERR_TRAVERSAL_OVERFLOW, "traversal stack overflow: frame invalid");
+    return RR_OK;
+}
+
+int rr_export_tiles(rr_context* ctx, void* d_dst)
+{
+    if (int r = use_device(ctx)) return r;
+    if (!d_dst) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_export_tiles: null destination");
+    if (!ctx->have_frame || ctx->frame_world < 2) return fail(ctx, RR_ERR_STATE, "rr_export_tiles: no sharded frame");
+    uint32_t tx, nt, local, mx;
+    tile_counts(ctx->W, ctx->H, ctx->tile_rank, ctx->frame_world, tx, nt, local, mx);
+    RR_HIP(hipMemcpyAsync(d_dst, ctx->d_rgba8, (size_t)mx * TILE * TILE * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    return RR_OK;
+}
+
+int rr_assemble_tiles(rr_context* ctx, const void* d_gathered, uint32_t world, void* d_frame)
+{
+    if (int r = use_device(ctx)) return r;
+    if (!d_gathered || world == 0) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_assemble_tiles: bad arguments");
+    if (!ctx->have_frame || ctx->W == 0) return fail(ctx, RR_ERR_STATE, "rr_assemble_tiles: dispatch first (frame size)");
+    uint32_t tx, nt, local, mx;
+    tile_counts(ctx->W, ctx->H, 0, world, tx, nt, local, mx);
+    uint32_t* dst = (uint32_t*)d_frame;
+    if (!dst) {
+        const size_t n = (size_t)ctx->W * ctx->H;
+        if (n > ctx->assembled_elems) {
+            RR_HIP(hipStreamSynchronize(ctx->stream));
+            dfree(ctx->d_assembled);
+            ctx->assembled_elems = 0;
+            RR_HIP(hipMalloc(&ctx->d_assembled, n * 4));
+            ctx->assembled_elems = n;
+        }
+        dst = ctx->d_assembled;
+    }
+    RR_HIP(launch_assemble_tiles((const uint32_t*)d_gathered, dst, ctx->W, ctx->H, tx, nt, world, mx, ctx->stream));
+    if (!d_frame) ctx->have_assembled = true;
+    return RR_OK;
+}
+
+int rr_get_stats(rr_context* ctx, rr_stats* out)
+{
+    if (int r = use_device(ctx)) return r;
+    if (!out) return RR_ERR_INVALID_ARGUMENT;
+    CounterBlock* h = (CounterBlock*)malloc(sizeof(CounterBlock));
+    if (!h) return RR_ERR_OUT_OF_MEMORY;
+    hipError_t e = hipMemcpyAsync(h, ctx->d_cnt, sizeof(CounterBlock), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { free(h); return fail(ctx, RR_ERR_DEVICE, "rr_get_stats", e); }
+    memset(out, 0, sizeof *out);
+    uint64_t rays = 0;
+    for (int i = 0; i < RAY_SHARDS; ++i) rays += h->shards[i];
+    out->rays = rays;
+    out->pixels = ctx->last_pixels;
+    out->primary = ctx->last_pixels;
+    out->secondary = rays - out->primary;
+    out->stats_valid = ctx->last_stats ? 1u : 0u;
+    if (ctx->last_stats) {
+        out->hits = h->counters[C_HITS]; out->misses = h->counters[C_MISSES]; out->terminal_hits = h->counters[C_TERMINAL];
+        out->tir = h->counters[C_TIR]; out->node_visits = h->counters[C_NODES]; out->tri_tests = h->counters[C_TRIS];
+    }
+    out->traversal_overflow = h->error;
+    out->bvh_depth = scene_stack_need(ctx);
+    free(h);
+    return RR_OK;
+}
+
+int rr_trace_rays(rr_context* ctx, const rr_ray* rays, uint32_t n, rr_hit* hits)
+{
+    if (int r = use_device(ctx)) return r;
+    if (!ctx->tlas_built) return fail(ctx, RR_ERR_STATE, "rr_trace_rays: build the BLAS and TLAS first");
+    if (n == 0) return RR_OK;
+    if (!rays || !hits) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_trace_rays: null arrays");
+    if (n > ctx->ray_cap) {
+        RR_HIP(hipStreamSynchronize(ctx->stream));
+        dfree(ctx->d_rays); dfree(ctx->d_hits);
+        ctx->ray_cap = 0;
+        RR_HIP(hipMalloc(&ctx->d_rays, (size_t)n * sizeof(rr_ray_dev)));
+        RR_HIP(hipMalloc(&ctx->d_hits, (size_t)n * sizeof(rr_hit_dev)));
+        ctx->ray_cap = n;
+    }
+    SceneDev sc;
+    fill_scene(ctx, sc);
+    RR_HIP(hipMemsetAsync(&ctx->d_cnt->error, 0, 4, ctx->stream));
+    RR_HIP(hipMemcpyAsync(ctx->d_rays, rays, (size_t)n * sizeof(rr_ray_dev), hipMemcpyHostToDevice, ctx->stream));
+    RR_HIP(launch_trace_rays(sc, ctx->d_rays, n, ctx->d_hits, &ctx->d_cnt->error, scene_stack_need(ctx) <= 32 ? 32 : 64, ctx->stream));
+    RR_HIP(hipMemcpyAsync(hits, ctx->d_hits, (size_t)n * sizeof(rr_hit_dev), hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t err = 0;
+    RR_HIP(hipMemcpyAsync(&err, &ctx->d_cnt->error, 4, hipMemcpyDeviceToHost, ctx->stream));
+    RR_HIP(hipStreamSynchronize(ctx->stream));
+    if (err) return fail(ctx, RR_ERR_TRAVERSAL_OVERFLOW, "traversal stack overflow");
+    return RR_OK;
+}
+
+int rr_download_blas(rr_context* ctx, uint32_t mesh_id, void* nodes, uint32_t* n_nodes, void* tris, uint32_t* n_tris)
+{
+    if (int r = use_device(ctx)) return r;
+    if (mesh_id >= ctx->meshes.size()) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_download_blas: unknown mesh id");
+    const MeshRes& m = ctx->meshes[mesh_id];
+    if (!m.built) return fail(ctx, RR_ERR_STATE, "rr_download_blas: BLAS not built");
+    const uint32_t nn = m.n_tris > 1 ? m.n_tris - 1 : 1;
+    if (n_nodes) *n_nodes = nn;
+    if (n_tris) *n_tris = m.n_tris;
+    RR_HIP(hipStreamSynchronize(ctx->stream));
+    if (nodes) RR_HIP(hipMemcpy(nodes, m.nodes, (size_t)nn * sizeof(BvhNode), hipMemcpyDeviceToHost));
+    if (tris) RR_HIP(hipMemcpy(tris, m.tris, (size_t)m.n_tris * sizeof(TriRec), hipMemcpyDeviceToHost));
+    return RR_OK;
+}
+
+} // extern "C"

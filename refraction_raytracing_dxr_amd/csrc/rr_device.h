@@ -1,0 +1,365 @@
+// rr_device.h -- gfx950 device code shared by the render and trace kernels:
+// fp32 vector helpers in the specified operation order, the DXR TraceRay stand-in
+// (LDS-stack BVH2 traversal + scaled Moller-Trumbore with face culling), and the
+// ClosestHit / Miss shading of RayTracing.hlsl:66-137.
+//
+// Arithmetic contract (DESIGN.md "Arithmetic"): compiled with -ffp-contract=off; every
+// fused multiply-add is an explicit fmaf; divide and sqrt are the correctly rounded
+// IEEE forms hipcc emits by default.  The box test is exempt (it only has to be
+// conservative); everything that decides a hit or a colour follows the written order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rr_types.h"
+
+namespace rr {
+
+struct f3 { float x, y, z; };
+
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ f3 scale3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ f3 cross3(f3 a, f3 b)
+{
+    return mk3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+__device__ __forceinline__ f3 normalize3(f3 a)
+{
+    float inv = 1.0f / sqrtf(dot3(a, a));
+    return scale3(a, inv);
+}
+
+// ---- spec'd atan2 / acos (Cephes single-precision minimax forms; HLSL's are implementation-defined)
+__device__ __forceinline__ float atan_pos(float x)
+{
+    float y0;
+    if (x > 2.414213562373095f) { y0 = 1.5707963267948966f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y0 = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+    else { y0 = 0.0f; }
+    float z = x * x;
+    float p = ((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f;
+    float r = p * z * x + x;
+    return y0 + r;
+}
+
+__device__ __forceinline__ float rr_atan2f(float y, float x)
+{
+    if (x != x || y != y) return __builtin_nanf("");
+    if (y == 0.0f) {
+        if (x > 0.0f || (x == 0.0f && !__builtin_signbit(x))) return y;
+        return __builtin_signbit(y) ? -3.14159265358979323846f : 3.14159265358979323846f;
+    }
+    if (x == 0.0f) return y > 0.0f ? 1.5707963267948966f : -1.5707963267948966f;
+    float a = atan_pos(fabsf(y) / fabsf(x));
+    if (x < 0.0f) a = 3.14159265358979323846f - a;
+    return y < 0.0f ? -a : a;
+}
+
+__device__ __forceinline__ float asin_core(float a)
+{
+    float z, x;
+    bool flag = a > 0.5f;
+    if (flag) { z = 0.5f * (1.0f - a); x = sqrtf(z); }
+    else { x = a; z = x * x; }
+    float p = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z
+               + 1.6666752422e-1f);
+    float r = p * z * x + x;
+    if (flag) { r = r + r; r = 1.5707963267948966f - r; }
+    return r;
+}
+
+__device__ __forceinline__ float rr_acosf(float x)
+{
+    if (!(x >= -1.0f && x <= 1.0f)) return __builtin_nanf("");
+    if (x < -0.5f) return 3.14159265358979323846f - 2.0f * asin_core(sqrtf(0.5f * (1.0f + x)));
+    if (x > 0.5f) return 2.0f * asin_core(sqrtf(0.5f * (1.0f - x)));
+    float s = asin_core(fabsf(x));
+    if (x < 0.0f) s = -s;
+    return 1.5707963267948966f - s;
+}
+
+// D3D ftou: truncate, NaN/negative -> 0, overflow -> 0xffffffff
+__device__ __forceinline__ uint32_t ftou(float f)
+{
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)f;
+}
+
+// typed UAV store to R8G8B8A8_UNORM (RefractionDemo.cpp:431)
+__device__ __forceinline__ uint32_t unorm8(float x)
+{
+    if (!(x > 0.0f)) return 0u;
+    if (x >= 1.0f) return 255u;
+    return (uint32_t)floorf(x * 255.0f + 0.5f);
+}
+
+// ---- TraceRay ------------------------------------------------------------------------------
+struct HitRec {
+    float t, U, V, ad;       // barycentric numerators scaled by |det|; u = U/ad, v = V/ad
+    uint32_t prim;           // PrimitiveIndex()
+    uint32_t leaf;           // index into TriRec/NrmRec (LBVH leaf order)
+    uint32_t inst;
+    bool hit;
+};
+
+struct TravCounters { uint32_t nodes, tris; };
+
+constexpr uint32_t CULL_BACK = 0x10u, CULL_FRONT = 0x20u;
+
+__device__ __forceinline__ float safe_rcp(float d)
+{
+    if (fabsf(d) < 1e-20f) d = copysignf(1e-20f, d);
+    return 1.0f / d;
+}
+
+// Box tests only.  A direction component that is (nearly) zero gets a huge finite reciprocal, so the
+// slab test on that axis degenerates to "is the origin inside [lo,hi]".  To keep that test inclusive
+// (a ray lying exactly in a box face must still reach the triangles in that face) the origin is
+// moved outwards by a few ulps on such an axis: lo planes are tested against lo, hi planes against hi.
+struct BoxOrigin { f3 lo, hi; };
+__device__ __forceinline__ float axis_pad(float o, float d)
+{
+    return fabsf(d) < 1e-20f ? fmaf(fabsf(o), 4.8e-7f, 1e-12f) : 0.0f;
+}
+__device__ __forceinline__ BoxOrigin box_origin(f3 O, f3 D)
+{
+    const float px = axis_pad(O.x, D.x), py = axis_pad(O.y, D.y), pz = axis_pad(O.z, D.z);
+    BoxOrigin b;
+    b.lo = mk3(O.x + px, O.y + py, O.z + pz);
+    b.hi = mk3(O.x - px, O.y - py, O.z - pz);
+    return b;
+}
+
+// scaled Moller-Trumbore; front-facing <=> det > 0.  Equal-t ties go to the lower
+// (instance, primitive) so that the result does not depend on traversal order.
+__device__ __forceinline__ void tri_test(const TriRec* __restrict__ tris, uint32_t leaf, f3 O, f3 D, float tmin,
+                                         uint32_t cull, uint32_t inst, HitRec& best)
+{
+    const float4* q = reinterpret_cast<const float4*>(tris + leaf);
+    float4 a = q[0], b = q[1], c = q[2];
+    f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
+    uint32_t prim = __float_as_uint(a.w);
+    f3 pv = cross3(D, e2);
+    float det = dot3(e1, pv);
+    if (cull & CULL_BACK) { if (!(det > 0.0f)) return; }
+    else if (cull & CULL_FRONT) { if (!(det < 0.0f)) return; }
+    else if (!(det != 0.0f)) return;
+    f3 tv = sub3(O, v0);
+    float U = dot3(tv, pv);
+    f3 qv = cross3(tv, e1);
+    float V = dot3(D, qv);
+    float T = dot3(e2, qv);
+    float ad = det;
+    if (det < 0.0f) { U = -U; V = -V; T = -T; ad = -det; }
+    if (U < 0.0f || V < 0.0f || U + V > ad) return;
+    float t = T / ad;
+    if (!(t > tmin)) return;
+    if (t < best.t || (t == best.t && best.hit && (inst < best.inst || (inst == best.inst && prim < best.prim)))) {
+        best.t = t; best.U = U; best.V = V; best.ad = ad; best.prim = prim; best.leaf = leaf; best.inst = inst;
+        best.hit = true;
+    }
+}
+
+// One BLAS.  stk: this lane's LDS stack column (entry e at stk[e*64]); sp0: entries already in use
+// (two-level traversal leaves the TLAS part of the stack below sp0).
+template <int STACK, bool STATS>
+__device__ __forceinline__ void trace_blas(const BlasDev& bl, f3 O, f3 D, float tmin, uint32_t cull, uint32_t inst,
+                                           HitRec& best, uint32_t* stk, int sp0, uint32_t* err, TravCounters& cnt)
+{
+    const f3 inv = mk3(safe_rcp(D.x), safe_rcp(D.y), safe_rcp(D.z));
+    const BoxOrigin bo = box_origin(O, D);
+    const float4* __restrict__ nodes = reinterpret_cast<const float4*>(bl.nodes);
+    int sp = sp0;
+    int node = 0;
+    for (;;) {
+        if (node >= 0) {
+            const float4* q = nodes + (size_t)node * 4;
+            float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            if (STATS) cnt.nodes++;
+            // child 0: lo (q0.x,q0.y,q0.z) hi (q0.w,q1.x,q1.y); child 1: lo (q1.z,q1.w,q2.x) hi (q2.y,q2.z,q2.w)
+            float a0x = (q0.x - bo.lo.x) * inv.x, b0x = (q0.w - bo.hi.x) * inv.x;
+            float a0y = (q0.y - bo.lo.y) * inv.y, b0y = (q1.x - bo.hi.y) * inv.y;
+            float a0z = (q0.z - bo.lo.z) * inv.z, b0z = (q1.y - bo.hi.z) * inv.z;
+            float a1x = (q1.z - bo.lo.x) * inv.x, b1x = (q2.y - bo.hi.x) * inv.x;
+            float a1y = (q1.w - bo.lo.y) * inv.y, b1y = (q2.z - bo.hi.y) * inv.y;
+            float a1z = (q2.x - bo.lo.z) * inv.z, b1z = (q2.w - bo.hi.z) * inv.z;
+            float tn0 = fmaxf(fmaxf(fminf(a0x, b0x), fminf(a0y, b0y)), fmaxf(fminf(a0z, b0z), tmin));
+            float tf0 = fminf(fminf(fmaxf(a0x, b0x), fmaxf(a0y, b0y)), fminf(fmaxf(a0z, b0z), best.t));
+            float tn1 = fmaxf(fmaxf(fminf(a1x, b1x), fminf(a1y, b1y)), fmaxf(fminf(a1z, b1z), tmin));
+            float tf1 = fminf(fminf(fmaxf(a1x, b1x), fmaxf(a1y, b1y)), fminf(fmaxf(a1z, b1z), best.t));
+            bool h0 = tn0 <= tf0 * 1.0000004f;
+            bool h1 = tn1 <= tf1 * 1.0000004f;
+            int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+            if (h0 && h1) {
+                bool swap = tn1 < tn0;
+                int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+                if (sp < STACK) stk[sp * 64] = (uint32_t)farc; else *err = 1u;
+                sp = sp < STACK ? sp + 1 : sp;
+                node = nearc;
+                continue;
+            }
+            if (h0 || h1) { node = h0 ? c0 : c1; continue; }
+        } else {
+            if (STATS) cnt.tris++;
+            tri_test(bl.tris, (uint32_t)~node, O, D, tmin, cull, inst, best);
+        }
+        if (sp == sp0) break;
+        --sp;
+        node = (int)stk[sp * 64];
+    }
+}
+
+__device__ __forceinline__ f3 xform_point(const float* m, f3 p)
+{
+    return mk3(((m[0] * p.x + m[1] * p.y) + m[2] * p.z) + m[3],
+               ((m[4] * p.x + m[5] * p.y) + m[6] * p.z) + m[7],
+               ((m[8] * p.x + m[9] * p.y) + m[10] * p.z) + m[11]);
+}
+__device__ __forceinline__ f3 xform_dir(const float* m, f3 p)
+{
+    return mk3((m[0] * p.x + m[1] * p.y) + m[2] * p.z,
+               (m[4] * p.x + m[5] * p.y) + m[6] * p.z,
+               (m[8] * p.x + m[9] * p.y) + m[10] * p.z);
+}
+
+// TraceRay(Scene, flags, 0xff, 0,0,0, ray, payload): closest hit over TLAS -> BLAS.
+template <int STACK, bool STATS, bool TLAS>
+__device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, float tmin, float tmax, uint32_t flags,
+                                            HitRec& best, uint32_t* stk, uint32_t* err, TravCounters& cnt)
+{
+    best.t = tmax; best.hit = false; best.prim = 0; best.leaf = 0; best.inst = 0; best.U = 0.0f; best.V = 0.0f;
+    best.ad = 1.0f;
+    if (!TLAS) {      // the reference's scene: one identity instance, mask 1, flags 0 (RefractionDemo.cpp:324-334)
+        trace_blas<STACK, STATS>(sc.blas0, O, D, tmin, flags, 0u, best, stk, 0, err, cnt);
+        return;
+    }
+    // two-level: the TLAS is a BVH2 of the same node type whose leaves are instance indices
+    const f3 inv = mk3(safe_rcp(D.x), safe_rcp(D.y), safe_rcp(D.z));
+    const BoxOrigin bo = box_origin(O, D);
+    const float4* __restrict__ nodes = reinterpret_cast<const float4*>(sc.tlas_nodes);
+    int sp = 0;
+    int node = 0;
+    for (;;) {
+        if (node >= 0) {
+            const float4* q = nodes + (size_t)node * 4;
+            float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            if (STATS) cnt.nodes++;
+            float a0x = (q0.x - bo.lo.x) * inv.x, b0x = (q0.w - bo.hi.x) * inv.x;
+            float a0y = (q0.y - bo.lo.y) * inv.y, b0y = (q1.x - bo.hi.y) * inv.y;
+            float a0z = (q0.z - bo.lo.z) * inv.z, b0z = (q1.y - bo.hi.z) * inv.z;
+            float a1x = (q1.z - bo.lo.x) * inv.x, b1x = (q2.y - bo.hi.x) * inv.x;
+            float a1y = (q1.w - bo.lo.y) * inv.y, b1y = (q2.z - bo.hi.y) * inv.y;
+            float a1z = (q2.x - bo.lo.z) * inv.z, b1z = (q2.w - bo.hi.z) * inv.z;
+            float tn0 = fmaxf(fmaxf(fminf(a0x, b0x), fminf(a0y, b0y)), fmaxf(fminf(a0z, b0z), tmin));
+            float tf0 = fminf(fminf(fmaxf(a0x, b0x), fmaxf(a0y, b0y)), fminf(fmaxf(a0z, b0z), best.t));
+            float tn1 = fmaxf(fmaxf(fminf(a1x, b1x), fminf(a1y, b1y)), fmaxf(fminf(a1z, b1z), tmin));
+            float tf1 = fminf(fminf(fmaxf(a1x, b1x), fmaxf(a1y, b1y)), fminf(fmaxf(a1z, b1z), best.t));
+            // instance boxes are transformed corner boxes (rounded): widen the acceptance a little more
+            bool h0 = tn0 <= tf0 * 1.000002f + 1e-6f;
+            bool h1 = tn1 <= tf1 * 1.000002f + 1e-6f;
+            int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+            if (h0 && h1) {
+                bool swap = tn1 < tn0;
+                int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+                if (sp < STACK) stk[sp * 64] = (uint32_t)farc; else *err = 1u;
+                sp = sp < STACK ? sp + 1 : sp;
+                node = nearc;
+                continue;
+            }
+            if (h0 || h1) { node = h0 ? c0 : c1; continue; }
+        } else {
+            uint32_t ii = (uint32_t)~node;
+            const InstDev& in = sc.insts[ii];
+            if (in.mask & 0xffu) {                       // InstanceInclusionMask 0xff
+                uint32_t f = flags;
+                if (in.flags & 0x1u) f &= ~(CULL_BACK | CULL_FRONT);
+                else if (in.flags & 0x2u) {
+                    if (f & CULL_BACK) f = (f & ~CULL_BACK) | CULL_FRONT;
+                    else if (f & CULL_FRONT) f = (f & ~CULL_FRONT) | CULL_BACK;
+                }
+                f3 Oo = O, Do = D;
+                if (!in.identity) { Oo = xform_point(in.inv, O); Do = xform_dir(in.inv, D); }
+                trace_blas<STACK, STATS>(in.blas, Oo, Do, tmin, f, ii, best, stk, sp, err, cnt);
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        node = (int)stk[sp * 64];
+    }
+}
+
+// ---- Miss: RayTracing.hlsl:127-137 -------------------------------------------------------------
+__device__ __forceinline__ f3 env_lookup(const SceneDev& sc, f3 r)
+{
+    if (!sc.env) return mk3(0.0f, 0.0f, 0.0f);
+    float at = rr_atan2f(r.x, r.z);
+    float ac = rr_acosf(r.y);
+    float theta = (float)sc.env_w * (at / 3.14159f + 1.0f) / 2;      // :133
+    float phi = (float)sc.env_h * (ac / 3.14159f);                   // :134
+    uint32_t ix = ftou(theta), iy = ftou(phi);                       // :135 operator[]: ftou, OOB reads 0
+    if (ix >= (uint32_t)sc.env_w || iy >= (uint32_t)sc.env_h) return mk3(0.0f, 0.0f, 0.0f);
+    float4 t = sc.env[(size_t)iy * (uint32_t)sc.env_w + ix];
+    return mk3(t.x, t.y, t.z);
+}
+
+// ---- ReflectRay / RefractRay: RayTracing.hlsl:66-76 ---------------------------------------------
+__device__ __forceinline__ f3 reflect_ray(f3 I, f3 N)
+{
+    float k = 2.0f * dot3(N, I);
+    return mk3(I.x - k * N.x, I.y - k * N.y, I.z - k * N.z);
+}
+
+__device__ __forceinline__ bool refract_ray(f3& R, f3 I, f3 N, float eta)
+{
+    float c = dot3(N, I);
+    float k = 1.0f - (eta * eta) * (1.0f - c * c);
+    if (k < 0.0f) return false;
+    float a = eta * c + sqrtf(k);
+    R = normalize3(mk3(eta * I.x - a * N.x, eta * I.y - a * N.y, eta * I.z - a * N.z));
+    return true;
+}
+
+// ---- GenerateCameraRay: RayTracing.hlsl:27-40 ----------------------------------------------------
+__device__ __forceinline__ f3 camera_ray_dir(const float* M, uint32_t x, uint32_t y, uint32_t W, uint32_t H)
+{
+    float px = (float)x + 0.5f, py = (float)y + 0.5f;
+    float sx = px / (float)W * 2.0f - 1.0f;
+    float sy = py / (float)H * 2.0f - 1.0f;
+    sy = -sy;
+    f3 R;
+    R.x = (sx * M[0] + sy * M[1]) + M[3];
+    R.y = (sx * M[4] + sy * M[5]) + M[7];
+    R.z = (sx * M[8] + sy * M[9]) + M[11];
+    return normalize3(R);
+}
+
+// shading normal of ClosestHit (RayTracing.hlsl:83-86); instance != identity: inverse-transpose
+// (extension, the reference's only instance is identity)
+template <bool TLAS>
+__device__ __forceinline__ f3 shading_normal(const SceneDev& sc, const HitRec& h)
+{
+    const BlasDev& bl = !TLAS ? sc.blas0 : sc.insts[h.inst].blas;
+    const float4* q = reinterpret_cast<const float4*>(bl.nrms + h.leaf);
+    float4 a = q[0], b = q[1], c = q[2];
+    float u = h.U / h.ad, v = h.V / h.ad;
+    f3 A = mk3(a.x, a.y, a.z);
+    f3 BA = sub3(mk3(b.x, b.y, b.z), A), CA = sub3(mk3(c.x, c.y, c.z), A);
+    f3 Nr = mk3(fmaf(v, CA.x, fmaf(u, BA.x, A.x)), fmaf(v, CA.y, fmaf(u, BA.y, A.y)), fmaf(v, CA.z, fmaf(u, BA.z, A.z)));
+    if (TLAS && !sc.insts[h.inst].identity) {
+        const float* w = sc.insts[h.inst].inv;
+        Nr = mk3((w[0] * Nr.x + w[4] * Nr.y) + w[8] * Nr.z,
+                 (w[1] * Nr.x + w[5] * Nr.y) + w[9] * Nr.z,
+                 (w[2] * Nr.x + w[6] * Nr.y) + w[10] * Nr.z);
+    }
+    return normalize3(Nr);
+}
+
+__device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+} // namespace rr

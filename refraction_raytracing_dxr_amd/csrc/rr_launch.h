@@ -1,0 +1,45 @@
+// rr_launch.h -- host-callable launchers of the gfx950 kernels (implemented in the .hip files)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rr_types.h"
+
+namespace rr {
+
+// device twins of rr_ray / rr_hit (include/rrdxr.h), same layout
+struct alignas(16) rr_ray_dev { float origin[3]; float tmin; float dir[3]; float tmax; uint32_t flags; uint32_t pad[3]; };
+struct rr_hit_dev { float t, u, v; uint32_t prim, inst, hit; };
+static_assert(sizeof(rr_ray_dev) == 48 && sizeof(rr_hit_dev) == 24, "ABI layout");
+
+// ---- rr_render.hip
+hipError_t launch_render_fused(const SceneDev& sc, const DispatchDev& a, int stack, int pend, bool stats, hipStream_t s);
+hipError_t launch_trace_rays(const SceneDev& sc, const rr_ray_dev* rays, uint32_t n, rr_hit_dev* hits, uint32_t* err,
+                             int stack, hipStream_t s);
+hipError_t launch_assemble_tiles(const uint32_t* gathered, uint32_t* frame, uint32_t W, uint32_t H, uint32_t tiles_x,
+                                 uint32_t n_tiles, uint32_t world, uint32_t max_tiles, hipStream_t s);
+
+// ---- rr_bvh_build.hip
+// Scratch + outputs of one LBVH build over n primitives (triangles of a mesh, or instances).
+struct BuildBuffers {
+    uint32_t n;                     // primitives
+    uint32_t n_pad;                 // next power of two >= n (sort width)
+    float*   prim_box;              // n * 6 (lo.xyz, hi.xyz) in primitive order
+    unsigned long long* keys;       // n_pad  (morton30 << 32 | prim)
+    int32_t* parent;                // (2n-1): [0,n-1) internal, [n-1, 2n-1) leaves (sorted order)
+    int32_t* child;                 // (n-1)*2 child refs
+    float*   node_box;              // (2n-1)*6 boxes, same indexing as parent
+    uint32_t* visit;                // (n-1) arrival counters
+    uint32_t* scene_box;            // 6 ordered-uint encodings of the scene bounds
+    uint32_t* depth;                // 1
+    BvhNode* nodes;                 // out: max(n-1,1)
+    uint32_t leaf_ref_prim;         // 0: leaf ref = ~sorted position (BLAS); 1: ~primitive index (TLAS)
+};
+
+hipError_t launch_tri_setup(const void* verts, const uint32_t* idx, uint32_t n_tris, const BuildBuffers& b, hipStream_t s);
+hipError_t launch_lbvh(const BuildBuffers& b, hipStream_t s);
+// after launch_lbvh: keys[i] & 0xffffffff is the primitive of sorted leaf i
+hipError_t launch_pack_tris(const void* verts, const uint32_t* idx, const BuildBuffers& b, TriRec* tris, NrmRec* nrms,
+                            hipStream_t s);
+hipError_t launch_inst_setup(const InstDev* insts, const float* blas_bounds, uint32_t n, const BuildBuffers& b, hipStream_t s);
+hipError_t launch_env_pad(const float* rgb, float4* out, uint32_t n_texels, hipStream_t s);
+
+} // namespace rr

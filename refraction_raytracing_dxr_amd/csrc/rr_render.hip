@@ -1,0 +1,243 @@
+// rr_render.hip -- the DispatchRays stand-in (RefractionDemo.cpp:580-594) for gfx950.
+//
+// One launch renders a frame: each lane owns a pixel and runs RayGen (RayTracing.hlsl:42-64),
+// then walks that pixel's whole ray tree depth-first -- ClosestHit (hlsl:79-125) spawns the
+// refracted child (followed immediately) and the reflected child (parked in registers),
+// Miss (hlsl:127-137) adds weight*texel.  The recursive "color += w * child.color" of the
+// shader becomes a path-weight sum taken in the same leaf order, so results are deterministic
+// and need no atomics, queues or second launch.  A wave covers an 8x8 pixel block (Morton lane
+// order) for BVH / env-map coherence; a 256-thread block covers a 32x8 strip of a 32x32 tile,
+// tiles are dealt round-robin to ranks (multi-GPU sharding), and the block->tile map keeps each
+// XCD on a contiguous run of tiles.
+#include <hip/hip_runtime.h>
+#include "rr_device.h"
+#include "rr_launch.h"
+
+namespace rr {
+
+struct PendRay {
+    float ox, oy, oz, dx, dy, dz, w;
+    uint32_t meta;          // count | outside << 16
+};
+
+__device__ __forceinline__ uint32_t compact1by1(uint32_t v)
+{
+    v &= 0x55555555u;
+    v = (v ^ (v >> 1)) & 0x33333333u;
+    v = (v ^ (v >> 2)) & 0x0f0f0f0fu;
+    return v;
+}
+
+// blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of
+// logical blocks so neighbouring strips/tiles share that XCD's L2 (bijective for any grid size)
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
+{
+    uint32_t q = n >> 3, r = n & 7u, xcd = b & 7u, slot = b >> 3;
+    uint32_t base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return base + slot;
+}
+
+template <int STACK, int PEND, bool STATS, bool TLAS>
+__global__ __launch_bounds__(256) void k_render_fused(SceneDev sc, DispatchDev a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t* stk = lds + wave * (STACK * 64) + lane;
+
+    const uint32_t lb = xcd_remap(blockIdx.x, a.n_blocks);
+    const uint32_t tile_local = lb >> 2, strip = lb & 3u;
+    const uint32_t tile = tile_local * a.tile_world + a.tile_rank;
+    const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const uint32_t lx = compact1by1(lane), ly = compact1by1(lane >> 1);
+    const uint32_t px = wave * 8u + lx, py = strip * 8u + ly;         // inside the 32x32 tile
+    const uint32_t x = tx * TILE + px, y = ty * TILE + py;
+    const bool valid = tile < a.n_tiles && x < a.W && y < a.H;
+
+    uint32_t n_rays = 0, n_hits = 0, n_miss = 0, n_term = 0, n_tir = 0;
+    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0;
+    uint32_t err = 0;
+
+    f3 acc = mk3(0.0f, 0.0f, 0.0f);
+    if (valid) {
+        PendRay pend[PEND];
+        int np = 0;
+        // RayGen: payload {color 0, mask 1, outside true, count 0}, CULL_BACK, [1e-4, 100]
+        f3 O = mk3(a.cam[0], a.cam[1], a.cam[2]);
+        f3 D = camera_ray_dir(a.M, x, y, a.W, a.H);
+        float w = 1.0f;
+        uint32_t count = 0;
+        bool outside = true;
+        float tmin = a.tmin_p, tmax = a.tmax_p;
+        for (;;) {
+            HitRec h;
+            trace_scene<STACK, STATS, TLAS>(sc, O, D, tmin, tmax, outside ? CULL_BACK : CULL_FRONT, h, stk, &err, cnt);
+            ++n_rays;
+            bool have_next = false;
+            if (!h.hit) {                                             // Miss
+                if (STATS) ++n_miss;
+                f3 e = env_lookup(sc, D);
+                acc.x = fmaf(w, e.x, acc.x); acc.y = fmaf(w, e.y, acc.y); acc.z = fmaf(w, e.z, acc.z);
+            } else {                                                  // ClosestHit
+                if (STATS) ++n_hits;
+                if ((int)count < a.max_refract) {                     // hlsl:82
+                    f3 N = shading_normal<TLAS>(sc, h);
+                    f3 X = mk3(fmaf(h.t, D.x, O.x), fmaf(h.t, D.y, O.y), fmaf(h.t, D.z, O.z));   // hlsl:88
+                    f3 Nf = outside ? N : neg3(N);
+                    const float R0 = (0.2f / 2.2f) * (0.2f / 2.2f);   // hlsl:92
+                    float b = 1.0f - dot3(D, Nf);                     // hlsl:93, pow(b,5) = b*b*b*b*b
+                    float b2 = b * b, b4 = b2 * b2;
+                    float R = (R0 * (1.0f - R0)) * (b4 * b);
+                    float eta = outside ? a.inv_ior : a.ior;          // hlsl:95
+                    f3 d1;
+                    bool refr = refract_ray(d1, D, Nf, eta);
+                    if (STATS && !refr) ++n_tir;
+                    bool refl = (int)count < a.max_reflect;           // hlsl:110
+                    f3 d2 = mk3(0.0f, 0.0f, 0.0f);
+                    if (refl) d2 = normalize3(reflect_ray(D, Nf));    // hlsl:113
+                    const uint32_t c1 = count + 1u;
+                    tmin = a.tmin_s; tmax = a.tmax_s;
+                    O = X;
+                    if (refr) {
+                        if (refl) {                                   // park the reflected child
+                            PendRay p;
+                            p.ox = X.x; p.oy = X.y; p.oz = X.z; p.dx = d2.x; p.dy = d2.y; p.dz = d2.z;
+                            p.w = w * R; p.meta = c1 | (outside ? 0x10000u : 0u);
+#pragma unroll
+                            for (int k = 0; k < PEND; ++k) if (k == np) pend[k] = p;
+                            ++np;
+                        }
+                        D = d1; w = w * (1.0f - R); count = c1; outside = !outside;   // hlsl:103-107
+                        have_next = true;
+                    } else if (refl) {
+                        D = d2; w = w * R; count = c1;                                // hlsl:118-122
+                        have_next = true;
+                    }
+                } else if (STATS) {
+                    ++n_term;                                         // payload.color stays 0
+                }
+            }
+            if (!have_next) {
+                if (np == 0) break;
+                --np;
+                PendRay p = pend[0];
+#pragma unroll
+                for (int k = 1; k < PEND; ++k) if (k == np) p = pend[k];
+                O = mk3(p.ox, p.oy, p.oz); D = mk3(p.dx, p.dy, p.dz); w = p.w;
+                count = p.meta & 0xffffu; outside = (p.meta & 0x10000u) != 0u;
+                tmin = a.tmin_s; tmax = a.tmax_s;
+            }
+        }
+        // RenderTarget[xy] = float4(color,1) -> R8G8B8A8_UNORM (hlsl:62)
+        const uint32_t packed = unorm8(acc.x) | (unorm8(acc.y) << 8) | (unorm8(acc.z) << 16) | 0xff000000u;
+        const size_t o = a.tile_world == 1u ? (size_t)y * a.W + x
+                                            : (size_t)tile_local * (TILE * TILE) + py * TILE + px;
+        a.out_rgba8[o] = packed;
+        if (a.out_f32) a.out_f32[o] = make_float4(acc.x, acc.y, acc.z, 1.0f);
+    }
+
+    // ray count: one sharded add per wave
+    uint32_t wr = wave_reduce_add(n_rays);
+    if (lane == 0 && wr) atomicAdd(&a.ray_shards[(blockIdx.x * 4u + wave) & (RAY_SHARDS - 1)], wr);
+    if (err) atomicOr(a.error_flag, 1u);
+    if (STATS) {
+        uint32_t v;
+        v = wave_reduce_add(n_hits);  if (lane == 0 && v) atomicAdd(&a.counters[C_HITS], (unsigned long long)v);
+        v = wave_reduce_add(n_miss);  if (lane == 0 && v) atomicAdd(&a.counters[C_MISSES], (unsigned long long)v);
+        v = wave_reduce_add(n_term);  if (lane == 0 && v) atomicAdd(&a.counters[C_TERMINAL], (unsigned long long)v);
+        v = wave_reduce_add(n_tir);   if (lane == 0 && v) atomicAdd(&a.counters[C_TIR], (unsigned long long)v);
+        v = wave_reduce_add(cnt.nodes); if (lane == 0 && v) atomicAdd(&a.counters[C_NODES], (unsigned long long)v);
+        v = wave_reduce_add(cnt.tris);  if (lane == 0 && v) atomicAdd(&a.counters[C_TRIS], (unsigned long long)v);
+        v = wave_reduce_add(valid ? 1u : 0u); if (lane == 0 && v) atomicAdd(&a.counters[C_PRIMARY], (unsigned long long)v);
+    }
+}
+
+// TraceRay in isolation, for the parity tests (rr_trace_rays)
+template <int STACK, bool TLAS>
+__global__ __launch_bounds__(256) void k_trace_rays(SceneDev sc, const rr_ray_dev* rays, uint32_t n, rr_hit_dev* hits,
+                                                    uint32_t* error_flag)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t* stk = lds + wave * (STACK * 64) + lane;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4* q = reinterpret_cast<const float4*>(rays + i);
+    float4 o = q[0], d = q[1];
+    uint32_t flags = rays[i].flags;
+    HitRec h;
+    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0;
+    uint32_t err = 0;
+    trace_scene<STACK, false, TLAS>(sc, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), o.w, d.w, flags, h, stk, &err, cnt);
+    rr_hit_dev r;
+    r.hit = h.hit ? 1u : 0u;
+    r.t = h.hit ? h.t : d.w;
+    r.u = h.hit ? h.U / h.ad : 0.0f;
+    r.v = h.hit ? h.V / h.ad : 0.0f;
+    r.prim = h.prim; r.inst = h.inst;
+    hits[i] = r;
+    if (err) atomicOr(error_flag, 1u);
+}
+
+// rank 0 after the RCCL gather: [world][max_tiles][32*32] RGBA8 -> W*H raster
+__global__ __launch_bounds__(256) void k_assemble_tiles(const uint32_t* __restrict__ gathered, uint32_t* __restrict__ frame,
+                                                        uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles,
+                                                        uint32_t world, uint32_t max_tiles)
+{
+    const uint32_t tile = blockIdx.x >> 2, strip = blockIdx.x & 3u;
+    if (tile >= n_tiles) return;
+    const uint32_t rank = tile % world, tile_local = tile / world;
+    const uint32_t px = threadIdx.x & 31u, py = strip * 8u + (threadIdx.x >> 5);
+    const uint32_t x = (tile % tiles_x) * TILE + px, y = (tile / tiles_x) * TILE + py;
+    if (x < W && y < H)
+        frame[(size_t)y * W + x] = gathered[((size_t)rank * max_tiles + tile_local) * (TILE * TILE) + py * TILE + px];
+}
+
+// ------------------------------------------------------------------------------------ launchers
+template <int STACK, int PEND, bool TLAS>
+static hipError_t launch_fused_spt(const SceneDev& sc, const DispatchDev& a, bool stats, hipStream_t s)
+{
+    const size_t lds = (size_t)4 * STACK * 64 * sizeof(uint32_t);
+    if (stats) hipLaunchKernelGGL((k_render_fused<STACK, PEND, true, TLAS>), dim3(a.n_blocks), dim3(256), lds, s, sc, a);
+    else       hipLaunchKernelGGL((k_render_fused<STACK, PEND, false, TLAS>), dim3(a.n_blocks), dim3(256), lds, s, sc, a);
+    return hipGetLastError();
+}
+
+template <int STACK, int PEND>
+static hipError_t launch_fused_sp(const SceneDev& sc, const DispatchDev& a, bool stats, hipStream_t s)
+{
+    return sc.single_identity ? launch_fused_spt<STACK, PEND, false>(sc, a, stats, s)
+                              : launch_fused_spt<STACK, PEND, true>(sc, a, stats, s);
+}
+
+hipError_t launch_render_fused(const SceneDev& sc, const DispatchDev& a, int stack, int pend, bool stats, hipStream_t s)
+{
+    if (a.n_blocks == 0) return hipSuccess;
+    if (stack <= 32) return pend <= 2 ? launch_fused_sp<32, 2>(sc, a, stats, s) : launch_fused_sp<32, 8>(sc, a, stats, s);
+    return pend <= 2 ? launch_fused_sp<64, 2>(sc, a, stats, s) : launch_fused_sp<64, 8>(sc, a, stats, s);
+}
+
+template <int STACK, bool TLAS>
+static void launch_trace_st(const SceneDev& sc, const rr_ray_dev* rays, uint32_t n, rr_hit_dev* hits, uint32_t* err, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_trace_rays<STACK, TLAS>), dim3((n + 255u) / 256u), dim3(256), 4 * STACK * 64 * 4, s, sc, rays, n, hits, err);
+}
+
+hipError_t launch_trace_rays(const SceneDev& sc, const rr_ray_dev* rays, uint32_t n, rr_hit_dev* hits, uint32_t* err,
+                             int stack, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    if (stack <= 32) { if (sc.single_identity) launch_trace_st<32, false>(sc, rays, n, hits, err, s); else launch_trace_st<32, true>(sc, rays, n, hits, err, s); }
+    else             { if (sc.single_identity) launch_trace_st<64, false>(sc, rays, n, hits, err, s); else launch_trace_st<64, true>(sc, rays, n, hits, err, s); }
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble_tiles(const uint32_t* gathered, uint32_t* frame, uint32_t W, uint32_t H, uint32_t tiles_x,
+                                 uint32_t n_tiles, uint32_t world, uint32_t max_tiles, hipStream_t s)
+{
+    if (n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_assemble_tiles, dim3(n_tiles * 4u), dim3(256), 0, s, gathered, frame, W, H, tiles_x, n_tiles, world,
+                       max_tiles);
+    return hipGetLastError();
+}
+
+} // namespace rr

@@ -1,0 +1,88 @@
+// rr_types.h -- records shared by the host side of the C ABI and the gfx950 kernels.
+//
+// HBM layout (all arrays 16-byte aligned, hipMalloc'ed once per mesh / scene):
+//   BvhNode  64 B  both child boxes + both child refs: ONE aligned half cache line per visit
+//   TriRec   48 B  v0,e1,e2 in LBVH leaf order, original PrimitiveIndex() in v0.w
+//   NrmRec   48 B  the three vertex normals of the same triangle (ClosestHit, RayTracing.hlsl:83-85)
+//   env      16 B  per texel (RGB32F padded to float4: one dwordx4 load per Miss)
+#pragma once
+#include <stdint.h>
+
+namespace rr {
+
+// child ref: >= 0 internal node index, < 0 leaf holding primitive ~ref (index into TriRec / instances)
+struct alignas(16) BvhNode {
+    float lo0[3], hi0[3];     // child 0 box
+    float lo1[3], hi1[3];     // child 1 box
+    int32_t c0, c1;
+    uint32_t pad0, pad1;
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 B");
+
+struct alignas(16) TriRec {
+    float v0[3]; uint32_t prim;
+    float e1[3]; uint32_t pad1;
+    float e2[3]; uint32_t pad2;
+};
+static_assert(sizeof(TriRec) == 48, "TriRec must be 48 B");
+
+struct alignas(16) NrmRec {
+    float nA[3]; float pad0;
+    float nB[3]; float pad1;
+    float nC[3]; float pad2;
+};
+static_assert(sizeof(NrmRec) == 48, "NrmRec must be 48 B");
+
+// one BLAS as the traversal kernels see it
+struct BlasDev {
+    const BvhNode* nodes;
+    const TriRec*  tris;
+    const NrmRec*  nrms;
+    uint32_t n_tris;
+    uint32_t depth;
+};
+
+// instance record for two-level traversal (derived from the 64-byte rr_instance_desc)
+struct alignas(16) InstDev {
+    float inv[12];            // world -> object 3x4
+    BlasDev blas;
+    uint32_t flags;           // RR_INSTANCE_FLAG_*
+    uint32_t mask;
+    uint32_t identity;
+    uint32_t pad;
+};
+
+struct SceneDev {
+    BlasDev  blas0;           // used directly when the scene is one identity instance (the reference's case)
+    const BvhNode* tlas_nodes;
+    const InstDev* insts;
+    uint32_t n_insts;
+    uint32_t single_identity; // 1: skip the top level entirely
+    const float4* env;        // w*h float4
+    int32_t env_w, env_h;
+};
+
+struct DispatchDev {
+    float M[16];              // proj_inv, CPU row-major bytes
+    float cam[4];
+    uint32_t W, H;
+    uint32_t tiles_x, n_tiles;      // 32x32 tiles over the frame
+    uint32_t tile_rank, tile_world;
+    uint32_t n_blocks;              // 4 blocks (32x8 strips) per local tile
+    int32_t max_refract, max_reflect;
+    float ior, inv_ior;
+    float tmin_p, tmax_p, tmin_s, tmax_s;
+    uint32_t* out_rgba8;            // world==1: W*H raster; else compact tiles
+    float4*   out_f32;              // optional, same addressing
+    unsigned long long* counters;   // rr::Counter slots
+    uint32_t* ray_shards;           // RAY_SHARDS u32 partial ray counts
+    uint32_t* error_flag;
+};
+
+enum Counter : int {
+    C_RAYS = 0, C_PRIMARY, C_SECONDARY, C_HITS, C_MISSES, C_TERMINAL, C_TIR, C_NODES, C_TRIS, C_COUNT
+};
+constexpr int RAY_SHARDS = 1024;
+constexpr int TILE = 32;
+
+} // namespace rr
