@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (primary + refracted/reflected) and fps at 1920x1080 on monkey.obj.
+
+A step = one frame of the reference's drawFrame loop: camera constants for the orbit angle,
+DispatchRays over the whole 1920x1080 frame, (N > 1: RCCL gather of the image tiles + de-interleave
+on rank 0).  Workload = BASELINE.json configs[2] (the configuration the metric is quoted on):
+monkey.obj (967 triangles, the reference's own file), 8 refraction bounces, 2 reflection bounces,
+seeded procedural 2048x1024 HDR env map (the reference's envmap.hdr is missing from the mount),
+frame k uses angle 0.01*(k+1) like the reference's `angle += 0.01f`.
+
+Run: python bench.py [--gpus N --steps K --warmup W]; for N > 1 the driver launches it through
+torch.distributed.run (one rank per GPU, backend nccl = RCCL over xGMI).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+
+W, H = 1920, 1080
+MAX_REFRACT, MAX_REFLECT = 8, 2
+ENV_W, ENV_H = 2048, 1024
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_bytes(st):
+    """Bytes the traversal/shading must touch (DESIGN.md 'Algorithmic bytes'): 64 B per internal node
+    visit, 48 B per triangle test, 36 B of vertex normals per shaded hit, 12 B env texel per miss,
+    4 B RGBA8 per pixel.  (SURVEY 8d additionally prices a ray queue and a float accumulator; the
+    fused kernel has neither, so they are left out -- this is the conservative figure.)"""
+    shaded = st.hits - st.terminal_hits
+    return 64 * st.node_visits + 48 * st.tri_tests + 36 * shaded + 12 * st.misses + 4 * st.pixels
+
+
+def survey_formula_bytes(st):
+    return (64 * st.node_visits + 48 * st.tri_tests + 96 * st.secondary + 36 * st.hits + 12 * st.misses
+            + 16 * st.pixels)
+
+
+def cpu_baseline(mesh, env, budget_s=15.0):
+    """The CPU oracle (oracle/, C, fp32, median-split BVH, one pthread per host core) timed on a
+    bounded sample of the same workload: whole 1920x1080 frames of the same orbit."""
+    import oracle as O
+    import refraction_raytracing_dxr_amd as rr
+    cores = os.cpu_count() or 1
+    s = O.Scene()
+    s.add_mesh(mesh.verts, mesh.indices)
+    s.set_envmap(env)
+    p = O.default_params(use_bvh=1, max_refract=MAX_REFRACT, max_reflect=MAX_REFLECT, accum_mode=0)
+    rays, frames, t0 = 0, 0, time.perf_counter()
+    while True:
+        sc = rr.camera_orbit(np.float32(0.01) * (frames + 1))
+        M, cam = np.array(sc.proj_inv, np.float32), np.array(sc.camera_loc, np.float32)
+        r = s.render(M, cam, W, H, p, threads=cores)
+        rays += r["stats"].rays
+        frames += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or frames >= 64:
+            break
+    return {"value": round(rays / el / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "%d full 1920x1080 frames of the same orbit (%.1f s), CPU restatement with its own "
+                      "median-split BVH; D3D12 WARP is Windows-only and cannot run here" % (frames, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames-per-gather", type=int, default=8)
+    args = ap.parse_args()
+
+    import torch
+    import refraction_raytracing_dxr_amd as rr
+    import oracle as O                      # only for asset paths and the cpu_baseline leg
+    from conftest import procedural_env
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    mesh = rr.Mesh()
+    assert mesh.load(O.asset("monkey.obj"))
+    env = procedural_env(ENV_W, ENV_H, seed=0)
+    r = rr.Renderer(local_rank)
+    r.set_stream(torch.cuda.current_stream().cuda_stream)       # so torch.cuda.synchronize() covers the kernels
+    r.load_scene(mesh.verts, mesh.indices, env)
+    params = rr.default_params(max_refract=MAX_REFRACT, max_reflect=MAX_REFLECT)
+    K, Wm = args.steps, args.warmup
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if world == 1:
+        r.set_tile_partition(0, 1)
+        r.render_orbit(W, H, Wm, angle=0.01, params=params)                 # warmup, untimed
+        barrier()
+        t0 = time.perf_counter()
+        r.timing_begin()
+        r.render_orbit(W, H, K, angle=0.01, params=params)                  # EXACTLY K timed steps
+        region_ms = r.timing_end()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        st = r.stats()
+        total_rays = st.rays
+        overflow = st.traversal_overflow
+    else:
+        sf = rr.dist.ShardedFrames(r, W, H, rank, world, torch.device("cuda", local_rank), args.frames_per_gather)
+        sf.render_orbit(Wm, angle=0.01, params=params)
+        barrier()
+        t0 = time.perf_counter()
+        rays_local = sf.render_orbit(K, angle=0.01, params=params)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        region_ms = None
+        t = torch.tensor([elapsed, float(rays_local), float(r.stats().traversal_overflow)], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        total_rays = int(t[1])
+        overflow = int(t[2])
+
+    # ---- roofline of the dominant kernel (k_render_fused), rank 0, single-GPU geometry ---------------------
+    roofline = None
+    cpu = None
+    if rank == 0:
+        r.set_tile_partition(0, 1)
+        n_prof = min(K, 200)
+        r.render_orbit(W, H, n_prof, angle=0.01, params=rr.default_params(
+            max_refract=MAX_REFRACT, max_reflect=MAX_REFLECT, flags=rr.DISPATCH_COLLECT_STATS))
+        sst = r.stats()                                                     # exact counters, summed over n_prof frames
+        r.render_orbit(W, H, n_prof, angle=0.01, params=rr.default_params(
+            max_refract=MAX_REFRACT, max_reflect=MAX_REFLECT, flags=rr.DISPATCH_TIME_KERNEL))
+        kms, kn = r.kernel_time()                                           # HIP events around each launch, on the launch stream
+        bytes_per_launch = algorithmic_bytes(sst) / n_prof
+        kernel_us = kms / kn * 1e3
+        achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "kernel": "k_render_fused", "kernel_us": round(kernel_us, 2),
+                    "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                    "bytes_per_ray": round(algorithmic_bytes(sst) / sst.rays, 1),
+                    "survey_formula_bytes_per_ray": round(survey_formula_bytes(sst) / sst.rays, 1),
+                    "node_visits_per_ray": round(sst.node_visits / sst.rays, 2),
+                    "tri_tests_per_ray": round(sst.tri_tests / sst.rays, 2),
+                    "kernel_grays_per_s": round(sst.rays / n_prof / (kernel_us * 1e-6) / 1e9, 3)}
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(mesh, env)
+
+    if rank == 0:
+        if overflow:
+            raise SystemExit("traversal stack overflow during the benchmark: result invalid")
+        out = {
+            "metric": "Mrays/s (primary+refracted) at 1920x1080, monkey.obj",
+            "value": round(total_rays / elapsed / 1e6, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": round(elapsed / K * 1e3, 5),
+            "fps": round(K / elapsed, 1),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "monkey.obj (967 tri) 1920x1080, 8 refraction / 2 reflection bounces, ior 1.3, "
+                                   "orbit angle 0.01*(k+1), seeded procedural 2048x1024 RGB32F env map",
+                       "rays_per_frame": round(total_rays / K, 1),
+                       "parallelism": "tiles32x32-roundrobin-x%d" % world,
+                       "frames_per_gather": args.frames_per_gather if world > 1 else None},
+            "device_region_ms_per_step": round(region_ms / K, 5) if region_ms is not None else None,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    r.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -77,6 +77,8 @@ typedef struct rr_dispatch_params {
 
 #define RR_DISPATCH_FLOAT_OUTPUT  0x1u  /* also keep the un-quantised float4 colour per pixel */
 #define RR_DISPATCH_COLLECT_STATS 0x2u  /* instrumented kernel: node/triangle/hit/miss counters */
+#define RR_DISPATCH_TIME_KERNEL   0x4u  /* bracket the render kernel with a HIP event pair (rr_kernel_time) */
+#define RR_DISPATCH_KEEP_COUNTERS 0x8u  /* do not zero the rr_get_stats counters first: keep accumulating */
 
 typedef struct rr_stats {
     uint64_t rays;                /* every TraceRay: primary + secondary */
@@ -88,7 +90,7 @@ typedef struct rr_stats {
     uint64_t tir;                 /* RefractRay returned false */
     uint64_t node_visits;         /* internal BVH nodes fetched (64 B each)  */
     uint64_t tri_tests;           /* triangle records fetched (48 B each)    */
-    uint64_t pixels;              /* pixels this context rendered in the last dispatch */
+    uint64_t pixels;              /* pixels this context rendered (last dispatch, or all frames of rr_render_orbit) */
     uint32_t stats_valid;         /* 1 if the last dispatch ran with RR_DISPATCH_COLLECT_STATS */
     uint32_t traversal_overflow;  /* sticky error flag of the last dispatch */
     uint32_t bvh_depth;           /* deepest BLAS / TLAS leaf */
@@ -161,6 +163,36 @@ int  rr_export_tiles(rr_context* ctx, void* d_dst);
 /* rank 0: de-interleave the gathered [world][max_tiles][4096 B] buffer into a W*H RGBA8 frame.
  * d_frame may be NULL (an internal frame is used; fetch it with rr_read_frame). */
 int  rr_assemble_tiles(rr_context* ctx, const void* d_gathered, uint32_t world, void* d_frame);
+
+/* drawFrame loop in C (RefractionDemo.cpp:557-567 + WinMain.cpp:49-59): n_frames times
+ * { camera constants for `angle`; rr_set_camera; rr_dispatch_rays; angle += angle_step }.
+ * Asynchronous; *angle is advanced like the reference's `static float angle`.  The counters
+ * of rr_get_stats accumulate over the n_frames (they are zeroed once, before the first). */
+int  rr_render_orbit(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispatch_params* params,
+                     float* angle, float angle_step, uint32_t n_frames,
+                     float fov_y, float aspect, float zn, float zf);
+
+/* The same loop for a sharded context (rr_set_tile_partition; world == 1 is allowed): frame f renders this rank's tiles straight into
+ * caller device memory at d_tiles + f*frame_stride_bytes (max_tiles_any_rank*4096 B each, tail
+ * zero-filled), i.e. into the send buffer of the RCCL gather, with no intermediate copy. */
+int  rr_render_orbit_sharded(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispatch_params* params,
+                             float* angle, float angle_step, uint32_t n_frames,
+                             float fov_y, float aspect, float zn, float zf,
+                             void* d_tiles, uint64_t frame_stride_bytes);
+/* rank 0, after gathering n_frames at once: frame f of rank r lies at
+ * d_gathered + r*rank_stride_bytes + f*frame_stride_bytes; writes n_frames W*H RGBA8 rasters to
+ * d_frames + f*out_stride_bytes.  One launch for all frames. */
+int  rr_assemble_frames(rr_context* ctx, const void* d_gathered, uint32_t world, uint64_t rank_stride_bytes,
+                        uint64_t frame_stride_bytes, uint32_t n_frames, uint32_t width, uint32_t height,
+                        void* d_frames, uint64_t out_stride_bytes);
+
+/* HIP-event timing on the stream the kernels run on.  rr_timing_begin records an event,
+ * rr_timing_end records another, waits for it and returns the elapsed milliseconds. */
+int  rr_timing_begin(rr_context* ctx);
+int  rr_timing_end(rr_context* ctx, float* elapsed_ms);
+/* sum and count of the render-kernel durations of all dispatches issued with
+ * RR_DISPATCH_TIME_KERNEL since the last call (blocks until they finished; at most 4096). */
+int  rr_kernel_time(rr_context* ctx, float* sum_ms, uint32_t* n_launches);
 
 /* exact counters of the last dispatch (blocks until it finished) */
 int  rr_get_stats(rr_context* ctx, rr_stats* out);

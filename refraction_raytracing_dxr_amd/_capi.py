@@ -13,6 +13,8 @@ STATUS_NAMES = {0: "RR_OK", 1: "RR_ERR_INVALID_ARGUMENT", 2: "RR_ERR_NO_DEVICE",
 
 DISPATCH_FLOAT_OUTPUT = 0x1
 DISPATCH_COLLECT_STATS = 0x2
+DISPATCH_TIME_KERNEL = 0x4
+DISPATCH_KEEP_COUNTERS = 0x8
 RAY_FLAG_CULL_BACK = 0x10
 RAY_FLAG_CULL_FRONT = 0x20
 INSTANCE_FLAG_CULL_DISABLE = 0x1
@@ -71,6 +73,16 @@ SYMBOLS = {
     "rr_export_tiles": (C.c_int, [_P, _P]),
     "rr_assemble_tiles": (C.c_int, [_P, _P, C.c_uint32, _P]),
     "rr_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
+    "rr_render_orbit": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(DispatchParams), C.POINTER(C.c_float),
+                                  C.c_float, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "rr_render_orbit_sharded": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(DispatchParams), C.POINTER(C.c_float),
+                                          C.c_float, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float, _P,
+                                          C.c_uint64]),
+    "rr_assemble_frames": (C.c_int, [_P, _P, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                     _P, C.c_uint64]),
+    "rr_timing_begin": (C.c_int, [_P]),
+    "rr_timing_end": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "rr_kernel_time": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "rr_trace_rays": (C.c_int, [_P, _P, C.c_uint32, _P]),
     "rr_download_blas": (C.c_int, [_P, C.c_uint32, _P, C.POINTER(C.c_uint32), _P, C.POINTER(C.c_uint32)]),
     "rr_default_dispatch_params": (None, [C.POINTER(DispatchParams)]),

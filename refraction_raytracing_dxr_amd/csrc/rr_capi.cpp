@@ -21,6 +21,8 @@
 
 using namespace rr;
 
+namespace rr { uint32_t host_sah_build(const float* verts, const uint32_t* idx, uint32_t n_tris, std::vector<BvhNode>& nodes, std::vector<uint32_t>& order); }
+
 static_assert(sizeof(rr_vertex) == 32, "Vertex stride (Mesh.cpp:45)");
 static_assert(sizeof(rr_instance_desc) == 64, "D3D12_RAYTRACING_INSTANCE_DESC");
 static_assert(sizeof(rr_scene_constants) == 80, "SceneConstants");
@@ -81,9 +83,17 @@ struct rr_context {
     size_t    rgba_elems = 0, f32_elems = 0, assembled_elems = 0;
     bool      have_f32 = false, have_frame = false, have_assembled = false;
     uint32_t  last_pixels = 0;
+    uint64_t  accum_pixels = 0;      // pixels of all dispatches since the counters were last zeroed
     bool      last_stats = false;
 
     CounterBlock* d_cnt = nullptr;
+
+    // timing
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    std::vector<hipEvent_t> kev;     // pairs
+    uint32_t kev_used = 0;
+    bool accumulate_counters = false;
+    uint32_t* ext_tiles = nullptr;   // rr_render_orbit_sharded: render straight into caller memory
 
     // trace_rays scratch
     rr_ray_dev* d_rays = nullptr;
@@ -259,6 +269,9 @@ int rr_destroy(rr_context* ctx)
     for (MeshRes& m : ctx->meshes) { dfree(m.d_verts); dfree(m.d_idx); dfree(m.nodes); dfree(m.tris); dfree(m.nrms); }
     dfree(ctx->d_env); dfree(ctx->d_insts); dfree(ctx->d_tlas); dfree(ctx->d_rgba8); dfree(ctx->d_f32);
     dfree(ctx->d_assembled); dfree(ctx->d_cnt); dfree(ctx->d_rays); dfree(ctx->d_hits);
+    if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+    if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return RR_OK;
@@ -339,13 +352,28 @@ int rr_build_blas(rr_context* ctx, uint32_t mesh_id)
     s.b.nodes = m.nodes;
     RR_HIP(launch_tri_setup(m.d_verts, m.d_idx, n, s.b, ctx->stream));
     RR_HIP(launch_lbvh(s.b, ctx->stream));
+    const char* dbg_bvh = getenv("RR_DEBUG_BVH");
+    uint32_t host_depth = 0;
+    if (dbg_bvh && !strcmp(dbg_bvh, "sah") && n > 1) {        // experiment: host full-sweep SAH hierarchy
+        std::vector<float> hv((size_t)m.n_verts * 8);
+        std::vector<uint32_t> hi(m.n_idx), order;
+        std::vector<BvhNode> hn;
+        RR_HIP(hipMemcpy(hv.data(), m.d_verts, hv.size() * 4, hipMemcpyDeviceToHost));
+        RR_HIP(hipMemcpy(hi.data(), m.d_idx, hi.size() * 4, hipMemcpyDeviceToHost));
+        host_depth = host_sah_build(hv.data(), hi.data(), n, hn, order);
+        std::vector<unsigned long long> keys(n);
+        for (uint32_t i = 0; i < n; ++i) keys[i] = order[i];
+        RR_HIP(hipStreamSynchronize(ctx->stream));
+        RR_HIP(hipMemcpy(s.b.keys, keys.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+        RR_HIP(hipMemcpy(m.nodes, hn.data(), hn.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
+    }
     RR_HIP(launch_pack_tris(m.d_verts, m.d_idx, s.b, m.tris, m.nrms, ctx->stream));
     uint32_t sb[6], depth = 0;
     RR_HIP(hipMemcpyAsync(sb, s.b.scene_box, sizeof sb, hipMemcpyDeviceToHost, ctx->stream));
     RR_HIP(hipMemcpyAsync(&depth, s.b.depth, 4, hipMemcpyDeviceToHost, ctx->stream));
     RR_HIP(hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < 6; ++k) m.bounds[k] = ord2f_host(sb[k]);
-    m.depth = depth;
+    m.depth = host_depth ? host_depth : depth;
     if (depth > 64) return fail(ctx, RR_ERR_UNSUPPORTED, "rr_build_blas: LBVH deeper than the 64-entry traversal stack");
     m.built = true;
     ctx->tlas_built = false;      // any TLAS built before refers to the old BLAS
@@ -490,24 +518,54 @@ int rr_dispatch_rays(rr_context* ctx, uint32_t width, uint32_t height, const rr_
     memcpy(a.cam, ctx->cam.camera_loc, 16);
     a.W = width; a.H = height; a.tiles_x = tiles_x; a.n_tiles = n_tiles;
     a.tile_rank = ctx->tile_rank; a.tile_world = ctx->tile_world;
-    a.n_blocks = local * 4u;
+    a.n_local_tiles = local;
+    a.n_blocks = ((local + 7u) & ~7u) * 4u;
+    a.compact_out = (ctx->tile_world > 1 || ctx->ext_tiles) ? 1u : 0u;
     a.max_refract = p.max_refract; a.max_reflect = p.max_reflect;
     a.ior = p.ior; a.inv_ior = 1.0f / p.ior;
     a.tmin_p = p.tmin_primary; a.tmax_p = p.tmax_primary; a.tmin_s = p.tmin_secondary; a.tmax_s = p.tmax_secondary;
-    a.out_rgba8 = ctx->d_rgba8;
+    a.out_rgba8 = ctx->ext_tiles ? ctx->ext_tiles : ctx->d_rgba8;
     a.out_f32 = want_f32 ? ctx->d_f32 : nullptr;
     a.counters = ctx->d_cnt->counters;
     a.ray_shards = ctx->d_cnt->shards;
     a.error_flag = &ctx->d_cnt->error;
+    a.diag = nullptr;
+    unsigned long long* d_diag = nullptr;
+    const char* diag_path = getenv("RR_DEBUG_DIAG");
+    if (diag_path && ctx->single_identity) { RR_HIP(hipMalloc(&d_diag, (size_t)a.n_blocks * 4 * 32)); a.diag = d_diag; }
 
     const bool stats = (p.flags & RR_DISPATCH_COLLECT_STATS) != 0;
     const uint32_t need = scene_stack_need(ctx);
-    RR_HIP(hipMemsetAsync(ctx->d_cnt, 0, sizeof(CounterBlock), ctx->stream));
-    if (ctx->tile_world > 1 && local < max_local)   // keep the gathered tail deterministic
-        RR_HIP(hipMemsetAsync(ctx->d_rgba8 + (size_t)local * TILE * TILE, 0, (size_t)(max_local - local) * TILE * TILE * 4, ctx->stream));
-    RR_HIP(launch_render_fused(sc, a, need <= 32 ? 32 : 64, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream));
+    const bool keep = ctx->accumulate_counters || (p.flags & RR_DISPATCH_KEEP_COUNTERS) != 0;
+    if (!keep) RR_HIP(hipMemsetAsync(ctx->d_cnt, 0, sizeof(CounterBlock), ctx->stream));
+    if (a.compact_out && local < max_local)   // keep the gathered tail deterministic
+        RR_HIP(hipMemsetAsync(a.out_rgba8 + (size_t)local * TILE * TILE, 0, (size_t)(max_local - local) * TILE * TILE * 4, ctx->stream));
+    const bool timed = (p.flags & RR_DISPATCH_TIME_KERNEL) != 0;
+    if (timed) {
+        if (ctx->kev_used >= 4096) return fail(ctx, RR_ERR_STATE, "rr_dispatch_rays: 4096 timed dispatches pending, call rr_kernel_time");
+        while (ctx->kev.size() < (size_t)(ctx->kev_used + 1) * 2) {
+            hipEvent_t e;
+            RR_HIP(hipEventCreate(&e));
+            ctx->kev.push_back(e);
+        }
+        RR_HIP(hipEventRecord(ctx->kev[(size_t)ctx->kev_used * 2], ctx->stream));
+    }
+    int stack_sel = need <= 16 ? 16 : need <= 24 ? 24 : need <= 32 ? 32 : 64;
+    if (const char* ov = getenv("RR_DEBUG_STACK")) stack_sel = atoi(ov);   // experiments only
+    RR_HIP(launch_render_fused(sc, a, stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream));
+    if (timed) {
+        RR_HIP(hipEventRecord(ctx->kev[(size_t)ctx->kev_used * 2 + 1], ctx->stream));
+        ++ctx->kev_used;
+    }
+    if (d_diag) {       // experiments only: dump per-wave {start, cycles, max rays per lane, loop trips}
+        std::vector<unsigned long long> h((size_t)a.n_blocks * 16);
+        RR_HIP(hipStreamSynchronize(ctx->stream));
+        RR_HIP(hipMemcpy(h.data(), d_diag, h.size() * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(d_diag);
+        if (FILE* f = fopen(diag_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+    }
     ctx->W = width; ctx->H = height; ctx->frame_world = ctx->tile_world;
-    ctx->have_f32 = want_f32; ctx->have_frame = true; ctx->have_assembled = false;
+    ctx->have_f32 = want_f32; ctx->have_frame = ctx->ext_tiles == nullptr; ctx->have_assembled = false;
     ctx->last_stats = stats;
     // pixels actually owned by this rank (partial edge tiles counted exactly)
     uint64_t px = 0;
@@ -517,6 +575,7 @@ int rr_dispatch_rays(rr_context* ctx, uint32_t width, uint32_t height, const rr_
         px += (uint64_t)w * h;
     }
     ctx->last_pixels = (uint32_t)px;
+    ctx->accum_pixels = (keep ? ctx->accum_pixels : 0) + px;
     return RR_OK;
 }
 
@@ -576,6 +635,108 @@ int rr_assemble_tiles(rr_context* ctx, const void* d_gathered, uint32_t world, v
     return RR_OK;
 }
 
+int rr_render_orbit(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispatch_params* params, float* angle,
+                    float angle_step, uint32_t n_frames, float fov_y, float aspect, float zn, float zf)
+{
+    if (int r = use_device(ctx)) return r;
+    if (!angle) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_render_orbit: null angle");
+    rr_dispatch_params p;
+    if (params) p = *params; else rr_default_dispatch_params(&p);
+    int rc = RR_OK;
+    for (uint32_t k = 0; k < n_frames && rc == RR_OK; ++k) {
+        rr_scene_constants sc;
+        rc = rr_host_camera_orbit(*angle, fov_y, aspect, zn, zf, &sc);          // RefractionDemo.cpp:559-565
+        if (rc != RR_OK) { fail(ctx, rc, "rr_render_orbit: camera"); break; }
+        ctx->cam = sc; ctx->cam_set = true;                                     // :566
+        *angle += angle_step;                                                   // :567
+        ctx->accumulate_counters = k > 0;      // counters are zeroed once, before the first frame
+        rc = rr_dispatch_rays(ctx, width, height, &p);                          // :580-594
+    }
+    ctx->accumulate_counters = false;
+    return rc;
+}
+
+int rr_render_orbit_sharded(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispatch_params* params, float* angle,
+                            float angle_step, uint32_t n_frames, float fov_y, float aspect, float zn, float zf,
+                            void* d_tiles, uint64_t frame_stride_bytes)
+{
+    if (int r = use_device(ctx)) return r;
+    if (!angle || !d_tiles) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_render_orbit_sharded: null argument");
+    uint32_t tx, nt, local, mx;
+    tile_counts(width ? width : 1, height ? height : 1, ctx->tile_rank, ctx->tile_world, tx, nt, local, mx);
+    if (frame_stride_bytes < (uint64_t)mx * TILE * TILE * 4 || (frame_stride_bytes & 3u))
+        return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_render_orbit_sharded: frame stride smaller than a tile buffer");
+    rr_dispatch_params p;
+    if (params) p = *params; else rr_default_dispatch_params(&p);
+    if (p.flags & RR_DISPATCH_FLOAT_OUTPUT) return fail(ctx, RR_ERR_UNSUPPORTED, "rr_render_orbit_sharded: RGBA8 tiles only");
+    const bool keep_first = (p.flags & RR_DISPATCH_KEEP_COUNTERS) != 0;
+    int rc = RR_OK;
+    for (uint32_t k = 0; k < n_frames && rc == RR_OK; ++k) {
+        rr_scene_constants sc;
+        rc = rr_host_camera_orbit(*angle, fov_y, aspect, zn, zf, &sc);
+        if (rc != RR_OK) { fail(ctx, rc, "rr_render_orbit_sharded: camera"); break; }
+        ctx->cam = sc; ctx->cam_set = true;
+        *angle += angle_step;
+        ctx->accumulate_counters = k > 0 || keep_first;
+        ctx->ext_tiles = (uint32_t*)((char*)d_tiles + (size_t)k * frame_stride_bytes);
+        rc = rr_dispatch_rays(ctx, width, height, &p);
+    }
+    ctx->ext_tiles = nullptr;
+    ctx->accumulate_counters = false;
+    return rc;
+}
+
+int rr_assemble_frames(rr_context* ctx, const void* d_gathered, uint32_t world, uint64_t rank_stride_bytes,
+                       uint64_t frame_stride_bytes, uint32_t n_frames, uint32_t width, uint32_t height, void* d_frames,
+                       uint64_t out_stride_bytes)
+{
+    if (int r = use_device(ctx)) return r;
+    if (!d_gathered || !d_frames || world == 0 || width == 0 || height == 0 || ((rank_stride_bytes | frame_stride_bytes | out_stride_bytes) & 3u))
+        return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_assemble_frames: bad arguments");
+    uint32_t tx, nt, local, mx;
+    tile_counts(width, height, 0, world, tx, nt, local, mx);
+    if (frame_stride_bytes < (uint64_t)mx * TILE * TILE * 4 || out_stride_bytes < (uint64_t)width * height * 4)
+        return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_assemble_frames: stride too small");
+    RR_HIP(launch_assemble_frames((const uint32_t*)d_gathered, (uint32_t*)d_frames, width, height, tx, nt, world,
+                                  rank_stride_bytes / 4, frame_stride_bytes / 4, out_stride_bytes / 4, n_frames, ctx->stream));
+    return RR_OK;
+}
+
+int rr_timing_begin(rr_context* ctx)
+{
+    if (int r = use_device(ctx)) return r;
+    if (!ctx->ev_begin) { RR_HIP(hipEventCreate(&ctx->ev_begin)); RR_HIP(hipEventCreate(&ctx->ev_end)); }
+    RR_HIP(hipEventRecord(ctx->ev_begin, ctx->stream));
+    return RR_OK;
+}
+
+int rr_timing_end(rr_context* ctx, float* elapsed_ms)
+{
+    if (int r = use_device(ctx)) return r;
+    if (!elapsed_ms || !ctx->ev_begin) return fail(ctx, RR_ERR_STATE, "rr_timing_end: rr_timing_begin first");
+    RR_HIP(hipEventRecord(ctx->ev_end, ctx->stream));
+    RR_HIP(hipEventSynchronize(ctx->ev_end));
+    RR_HIP(hipEventElapsedTime(elapsed_ms, ctx->ev_begin, ctx->ev_end));
+    return RR_OK;
+}
+
+int rr_kernel_time(rr_context* ctx, float* sum_ms, uint32_t* n_launches)
+{
+    if (int r = use_device(ctx)) return r;
+    if (!sum_ms || !n_launches) return RR_ERR_INVALID_ARGUMENT;
+    RR_HIP(hipStreamSynchronize(ctx->stream));
+    double sum = 0.0;
+    for (uint32_t i = 0; i < ctx->kev_used; ++i) {
+        float ms = 0.0f;
+        RR_HIP(hipEventElapsedTime(&ms, ctx->kev[(size_t)i * 2], ctx->kev[(size_t)i * 2 + 1]));
+        sum += ms;
+    }
+    *sum_ms = (float)sum;
+    *n_launches = ctx->kev_used;
+    ctx->kev_used = 0;
+    return RR_OK;
+}
+
 int rr_get_stats(rr_context* ctx, rr_stats* out)
 {
     if (int r = use_device(ctx)) return r;
@@ -589,8 +750,8 @@ int rr_get_stats(rr_context* ctx, rr_stats* out)
     uint64_t rays = 0;
     for (int i = 0; i < RAY_SHARDS; ++i) rays += h->shards[i];
     out->rays = rays;
-    out->pixels = ctx->last_pixels;
-    out->primary = ctx->last_pixels;
+    out->pixels = ctx->accum_pixels;
+    out->primary = ctx->accum_pixels;
     out->secondary = rays - out->primary;
     out->stats_valid = ctx->last_stats ? 1u : 0u;
     if (ctx->last_stats) {

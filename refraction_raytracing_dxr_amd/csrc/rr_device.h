@@ -108,29 +108,56 @@ struct TravCounters { uint32_t nodes, tris; };
 
 constexpr uint32_t CULL_BACK = 0x10u, CULL_FRONT = 0x20u;
 
-__device__ __forceinline__ float safe_rcp(float d)
+// ---- box-test ray setup ----------------------------------------------------------------------------
+// The box test is exempt from the arithmetic contract: it only has to be CONSERVATIVE (never cull a
+// box that holds a triangle the exact-order triangle test would accept).  Slabs are evaluated as
+// t = fma(plane, inv, -(O*inv)) with a hardware reciprocal; the rounding of that form
+// (<= |t|*2^-22 + |O*inv|*2^-24) is covered by moving the near planes earlier and the far planes later
+// by pad = |O*inv|*2^-22 + |inv|*1e-12 (i.e. the box grows by 1e-12 world units), folded into the
+// per-ray constants, plus a relative 2^-20 on t_far.  A (nearly) zero direction component gets
+// inv = +-1e20: pad is then >= 1e8, so the slab on that axis only rejects origins clearly outside
+// it -- rays lying exactly in a box face stay conservative.
+struct BoxRay {
+    f3 inv;        // 1/D (approximate)
+    f3 klo, khi;   // additive constants for the lo / hi planes: -(O*inv) -/+ sign(inv)*pad
+};
+__device__ __forceinline__ void box_axis(float o, float d, float& inv, float& klo, float& khi)
 {
-    if (fabsf(d) < 1e-20f) d = copysignf(1e-20f, d);
-    return 1.0f / d;
+    const float dg = fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d;
+    inv = __builtin_amdgcn_rcpf(dg);
+    const float oi = -(o * inv);
+    const float pad = copysignf(fmaf(fabsf(oi), 2.4e-7f, fabsf(inv) * 1e-12f), inv);
+    klo = oi - pad;
+    khi = oi + pad;
+}
+__device__ __forceinline__ BoxRay box_ray(f3 O, f3 D)
+{
+    BoxRay r;
+    box_axis(O.x, D.x, r.inv.x, r.klo.x, r.khi.x);
+    box_axis(O.y, D.y, r.inv.y, r.klo.y, r.khi.y);
+    box_axis(O.z, D.z, r.inv.z, r.klo.z, r.khi.z);
+    return r;
+}
+// slab test of one box; returns entry distance in tn
+__device__ __forceinline__ bool box_hit(const BoxRay& r, float lx, float ly, float lz, float hx, float hy, float hz,
+                                        float tmin, float tmax, float& tn)
+{
+    const float ax = fmaf(lx, r.inv.x, r.klo.x), bx = fmaf(hx, r.inv.x, r.khi.x);
+    const float ay = fmaf(ly, r.inv.y, r.klo.y), by = fmaf(hy, r.inv.y, r.khi.y);
+    const float az = fmaf(lz, r.inv.z, r.klo.z), bz = fmaf(hz, r.inv.z, r.khi.z);
+    tn = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), tmin);
+    const float tf = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)), tmax);
+    return tn <= tf * 1.000001f;
 }
 
-// Box tests only.  A direction component that is (nearly) zero gets a huge finite reciprocal, so the
-// slab test on that axis degenerates to "is the origin inside [lo,hi]".  To keep that test inclusive
-// (a ray lying exactly in a box face must still reach the triangles in that face) the origin is
-// moved outwards by a few ulps on such an axis: lo planes are tested against lo, hi planes against hi.
-struct BoxOrigin { f3 lo, hi; };
-__device__ __forceinline__ float axis_pad(float o, float d)
+// diagnostic builds count wave-level loop trips in LDS (one word per wave); null in product builds
+struct Diag { uint32_t* trips; };
+__device__ __forceinline__ void diag_trip(const Diag& d)
 {
-    return fabsf(d) < 1e-20f ? fmaf(fabsf(o), 4.8e-7f, 1e-12f) : 0.0f;
+    if (d.trips) { const unsigned long long m = __ballot(1); if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) *d.trips += 1u; }
 }
-__device__ __forceinline__ BoxOrigin box_origin(f3 O, f3 D)
-{
-    const float px = axis_pad(O.x, D.x), py = axis_pad(O.y, D.y), pz = axis_pad(O.z, D.z);
-    BoxOrigin b;
-    b.lo = mk3(O.x + px, O.y + py, O.z + pz);
-    b.hi = mk3(O.x - px, O.y - py, O.z - pz);
-    return b;
-}
+
+constexpr int TRAV_DONE = (int)0x80000000;     // neither an internal index (>= 0) nor a leaf (~i with i < 2^31-1)
 
 // scaled Moller-Trumbore; front-facing <=> det > 0.  Equal-t ties go to the lower
 // (instance, primitive) so that the result does not depend on traversal order.
@@ -164,50 +191,48 @@ __device__ __forceinline__ void tri_test(const TriRec* __restrict__ tris, uint32
 
 // One BLAS.  stk: this lane's LDS stack column (entry e at stk[e*64]); sp0: entries already in use
 // (two-level traversal leaves the TLAS part of the stack below sp0).
+// "while-while" form: all lanes first descend internal nodes (near child first, far child pushed)
+// until every lane of the wave holds a leaf or has finished; only then is the (expensive) triangle
+// test executed, once, for all lanes that hold a leaf.
 template <int STACK, bool STATS>
 __device__ __forceinline__ void trace_blas(const BlasDev& bl, f3 O, f3 D, float tmin, uint32_t cull, uint32_t inst,
-                                           HitRec& best, uint32_t* stk, int sp0, uint32_t* err, TravCounters& cnt)
+                                           HitRec& best, uint32_t* stk, int sp0, uint32_t* err, TravCounters& cnt,
+                                           const Diag dg = Diag{ nullptr })
 {
-    const f3 inv = mk3(safe_rcp(D.x), safe_rcp(D.y), safe_rcp(D.z));
-    const BoxOrigin bo = box_origin(O, D);
+    const BoxRay br = box_ray(O, D);
     const float4* __restrict__ nodes = reinterpret_cast<const float4*>(bl.nodes);
     int sp = sp0;
     int node = 0;
     for (;;) {
-        if (node >= 0) {
-            const float4* q = nodes + (size_t)node * 4;
-            float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        while (node >= 0) {
+            diag_trip(dg);
+            const float4* q = nodes + (uint32_t)node * 4u;
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             if (STATS) cnt.nodes++;
             // child 0: lo (q0.x,q0.y,q0.z) hi (q0.w,q1.x,q1.y); child 1: lo (q1.z,q1.w,q2.x) hi (q2.y,q2.z,q2.w)
-            float a0x = (q0.x - bo.lo.x) * inv.x, b0x = (q0.w - bo.hi.x) * inv.x;
-            float a0y = (q0.y - bo.lo.y) * inv.y, b0y = (q1.x - bo.hi.y) * inv.y;
-            float a0z = (q0.z - bo.lo.z) * inv.z, b0z = (q1.y - bo.hi.z) * inv.z;
-            float a1x = (q1.z - bo.lo.x) * inv.x, b1x = (q2.y - bo.hi.x) * inv.x;
-            float a1y = (q1.w - bo.lo.y) * inv.y, b1y = (q2.z - bo.hi.y) * inv.y;
-            float a1z = (q2.x - bo.lo.z) * inv.z, b1z = (q2.w - bo.hi.z) * inv.z;
-            float tn0 = fmaxf(fmaxf(fminf(a0x, b0x), fminf(a0y, b0y)), fmaxf(fminf(a0z, b0z), tmin));
-            float tf0 = fminf(fminf(fmaxf(a0x, b0x), fmaxf(a0y, b0y)), fminf(fmaxf(a0z, b0z), best.t));
-            float tn1 = fmaxf(fmaxf(fminf(a1x, b1x), fminf(a1y, b1y)), fmaxf(fminf(a1z, b1z), tmin));
-            float tf1 = fminf(fminf(fmaxf(a1x, b1x), fmaxf(a1y, b1y)), fminf(fmaxf(a1z, b1z), best.t));
-            bool h0 = tn0 <= tf0 * 1.0000004f;
-            bool h1 = tn1 <= tf1 * 1.0000004f;
-            int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+            float tn0, tn1;
+            const bool h0 = box_hit(br, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmin, best.t, tn0);
+            const bool h1 = box_hit(br, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmin, best.t, tn1);
+            const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
             if (h0 && h1) {
-                bool swap = tn1 < tn0;
-                int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
-                if (sp < STACK) stk[sp * 64] = (uint32_t)farc; else *err = 1u;
-                sp = sp < STACK ? sp + 1 : sp;
-                node = nearc;
-                continue;
+                const bool swap = tn1 < tn0;
+                const int farc = swap ? c0 : c1;
+                node = swap ? c1 : c0;
+                if (sp < STACK) { stk[sp * 64] = (uint32_t)farc; ++sp; } else *err = 1u;
+            } else if (h0 || h1) {
+                node = h0 ? c0 : c1;
+            } else if (sp > sp0) {
+                --sp;
+                node = (int)stk[sp * 64];
+            } else {
+                node = TRAV_DONE;
             }
-            if (h0 || h1) { node = h0 ? c0 : c1; continue; }
-        } else {
-            if (STATS) cnt.tris++;
-            tri_test(bl.tris, (uint32_t)~node, O, D, tmin, cull, inst, best);
         }
-        if (sp == sp0) break;
-        --sp;
-        node = (int)stk[sp * 64];
+        if (node == TRAV_DONE) break;
+        diag_trip(dg);
+        if (STATS) cnt.tris++;
+        tri_test(bl.tris, (uint32_t)~node, O, D, tmin, cull, inst, best);
+        if (sp > sp0) { --sp; node = (int)stk[sp * 64]; } else node = TRAV_DONE;
     }
 }
 
@@ -227,50 +252,50 @@ __device__ __forceinline__ f3 xform_dir(const float* m, f3 p)
 // TraceRay(Scene, flags, 0xff, 0,0,0, ray, payload): closest hit over TLAS -> BLAS.
 template <int STACK, bool STATS, bool TLAS>
 __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, float tmin, float tmax, uint32_t flags,
-                                            HitRec& best, uint32_t* stk, uint32_t* err, TravCounters& cnt)
+                                            HitRec& best, uint32_t* stk, uint32_t* err, TravCounters& cnt,
+                                            const Diag dg = Diag{ nullptr })
 {
     best.t = tmax; best.hit = false; best.prim = 0; best.leaf = 0; best.inst = 0; best.U = 0.0f; best.V = 0.0f;
     best.ad = 1.0f;
     if (!TLAS) {      // the reference's scene: one identity instance, mask 1, flags 0 (RefractionDemo.cpp:324-334)
-        trace_blas<STACK, STATS>(sc.blas0, O, D, tmin, flags, 0u, best, stk, 0, err, cnt);
+        trace_blas<STACK, STATS>(sc.blas0, O, D, tmin, flags, 0u, best, stk, 0, err, cnt, dg);
         return;
     }
     // two-level: the TLAS is a BVH2 of the same node type whose leaves are instance indices
-    const f3 inv = mk3(safe_rcp(D.x), safe_rcp(D.y), safe_rcp(D.z));
-    const BoxOrigin bo = box_origin(O, D);
+    const BoxRay br = box_ray(O, D);
     const float4* __restrict__ nodes = reinterpret_cast<const float4*>(sc.tlas_nodes);
     int sp = 0;
     int node = 0;
     for (;;) {
-        if (node >= 0) {
-            const float4* q = nodes + (size_t)node * 4;
-            float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        while (node >= 0) {
+            const float4* q = nodes + (uint32_t)node * 4u;
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             if (STATS) cnt.nodes++;
-            float a0x = (q0.x - bo.lo.x) * inv.x, b0x = (q0.w - bo.hi.x) * inv.x;
-            float a0y = (q0.y - bo.lo.y) * inv.y, b0y = (q1.x - bo.hi.y) * inv.y;
-            float a0z = (q0.z - bo.lo.z) * inv.z, b0z = (q1.y - bo.hi.z) * inv.z;
-            float a1x = (q1.z - bo.lo.x) * inv.x, b1x = (q2.y - bo.hi.x) * inv.x;
-            float a1y = (q1.w - bo.lo.y) * inv.y, b1y = (q2.z - bo.hi.y) * inv.y;
-            float a1z = (q2.x - bo.lo.z) * inv.z, b1z = (q2.w - bo.hi.z) * inv.z;
-            float tn0 = fmaxf(fmaxf(fminf(a0x, b0x), fminf(a0y, b0y)), fmaxf(fminf(a0z, b0z), tmin));
-            float tf0 = fminf(fminf(fmaxf(a0x, b0x), fmaxf(a0y, b0y)), fminf(fmaxf(a0z, b0z), best.t));
-            float tn1 = fmaxf(fmaxf(fminf(a1x, b1x), fminf(a1y, b1y)), fmaxf(fminf(a1z, b1z), tmin));
-            float tf1 = fminf(fminf(fmaxf(a1x, b1x), fmaxf(a1y, b1y)), fminf(fmaxf(a1z, b1z), best.t));
-            // instance boxes are transformed corner boxes (rounded): widen the acceptance a little more
-            bool h0 = tn0 <= tf0 * 1.000002f + 1e-6f;
-            bool h1 = tn1 <= tf1 * 1.000002f + 1e-6f;
-            int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+            // instance boxes are boxes of transformed corners (rounded): grow them by a few ulps
+            float tn0, tn1;
+            const float g = 1e-5f;
+            const bool h0 = box_hit(br, q0.x - g * fabsf(q0.x), q0.y - g * fabsf(q0.y), q0.z - g * fabsf(q0.z),
+                                    q0.w + g * fabsf(q0.w), q1.x + g * fabsf(q1.x), q1.y + g * fabsf(q1.y), tmin, best.t, tn0);
+            const bool h1 = box_hit(br, q1.z - g * fabsf(q1.z), q1.w - g * fabsf(q1.w), q2.x - g * fabsf(q2.x),
+                                    q2.y + g * fabsf(q2.y), q2.z + g * fabsf(q2.z), q2.w + g * fabsf(q2.w), tmin, best.t, tn1);
+            const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
             if (h0 && h1) {
-                bool swap = tn1 < tn0;
-                int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
-                if (sp < STACK) stk[sp * 64] = (uint32_t)farc; else *err = 1u;
-                sp = sp < STACK ? sp + 1 : sp;
-                node = nearc;
-                continue;
+                const bool swap = tn1 < tn0;
+                const int farc = swap ? c0 : c1;
+                node = swap ? c1 : c0;
+                if (sp < STACK) { stk[sp * 64] = (uint32_t)farc; ++sp; } else *err = 1u;
+            } else if (h0 || h1) {
+                node = h0 ? c0 : c1;
+            } else if (sp > 0) {
+                --sp;
+                node = (int)stk[sp * 64];
+            } else {
+                node = TRAV_DONE;
             }
-            if (h0 || h1) { node = h0 ? c0 : c1; continue; }
-        } else {
-            uint32_t ii = (uint32_t)~node;
+        }
+        if (node == TRAV_DONE) break;
+        {
+            const uint32_t ii = (uint32_t)~node;
             const InstDev& in = sc.insts[ii];
             if (in.mask & 0xffu) {                       // InstanceInclusionMask 0xff
                 uint32_t f = flags;
@@ -284,9 +309,7 @@ __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, floa
                 trace_blas<STACK, STATS>(in.blas, Oo, Do, tmin, f, ii, best, stk, sp, err, cnt);
             }
         }
-        if (sp == 0) break;
-        --sp;
-        node = (int)stk[sp * 64];
+        if (sp > 0) { --sp; node = (int)stk[sp * 64]; } else node = TRAV_DONE;
     }
 }
 

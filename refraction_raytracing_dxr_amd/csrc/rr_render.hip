@@ -10,6 +10,8 @@
 // tiles are dealt round-robin to ranks (multi-GPU sharding), and the block->tile map keeps each
 // XCD on a contiguous run of tiles.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
 #include "rr_device.h"
 #include "rr_launch.h"
 
@@ -28,30 +30,36 @@ __device__ __forceinline__ uint32_t compact1by1(uint32_t v)
     return v;
 }
 
-// blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of
-// logical blocks so neighbouring strips/tiles share that XCD's L2 (bijective for any grid size)
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
+// Blocks b and b+8 share an XCD (round-robin dispatch).  The four 32x8 strips of a tile go to one XCD
+// (they share BVH subtrees and env-map lines in that XCD's L2) while consecutive tiles go to
+// consecutive XCDs: coverage is centre-heavy (the mesh fills ~7 % of the frame but owns a third of
+// the rays), so giving an XCD a contiguous image region would leave most of the chip idle.
+__device__ __forceinline__ void block_to_tile(uint32_t b, uint32_t& tile_local, uint32_t& strip)
 {
-    uint32_t q = n >> 3, r = n & 7u, xcd = b & 7u, slot = b >> 3;
-    uint32_t base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
-    return base + slot;
+    const uint32_t xcd = b & 7u, slot = b >> 3;
+    tile_local = (slot >> 2) * 8u + xcd;
+    strip = slot & 3u;
 }
 
-template <int STACK, int PEND, bool STATS, bool TLAS>
+template <int STACK, int PEND, bool STATS, bool TLAS, bool DIAG = false>
 __global__ __launch_bounds__(256) void k_render_fused(SceneDev sc, DispatchDev a)
 {
+    __shared__ uint32_t diag_trips[4];
+    const unsigned long long diag_t0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
+    if (DIAG && threadIdx.x < 4) diag_trips[threadIdx.x] = 0;
+    if (DIAG) __syncthreads();
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t* stk = lds + wave * (STACK * 64) + lane;
 
-    const uint32_t lb = xcd_remap(blockIdx.x, a.n_blocks);
-    const uint32_t tile_local = lb >> 2, strip = lb & 3u;
+    uint32_t tile_local, strip;
+    block_to_tile(blockIdx.x, tile_local, strip);
     const uint32_t tile = tile_local * a.tile_world + a.tile_rank;
     const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     const uint32_t lx = compact1by1(lane), ly = compact1by1(lane >> 1);
     const uint32_t px = wave * 8u + lx, py = strip * 8u + ly;         // inside the 32x32 tile
     const uint32_t x = tx * TILE + px, y = ty * TILE + py;
-    const bool valid = tile < a.n_tiles && x < a.W && y < a.H;
+    const bool valid = tile_local < a.n_local_tiles && x < a.W && y < a.H;
 
     uint32_t n_rays = 0, n_hits = 0, n_miss = 0, n_term = 0, n_tir = 0;
     TravCounters cnt; cnt.nodes = 0; cnt.tris = 0;
@@ -70,7 +78,8 @@ __global__ __launch_bounds__(256) void k_render_fused(SceneDev sc, DispatchDev a
         float tmin = a.tmin_p, tmax = a.tmax_p;
         for (;;) {
             HitRec h;
-            trace_scene<STACK, STATS, TLAS>(sc, O, D, tmin, tmax, outside ? CULL_BACK : CULL_FRONT, h, stk, &err, cnt);
+            trace_scene<STACK, STATS, TLAS>(sc, O, D, tmin, tmax, outside ? CULL_BACK : CULL_FRONT, h, stk, &err, cnt,
+                                            Diag{ DIAG ? &diag_trips[threadIdx.x >> 6] : nullptr });
             ++n_rays;
             bool have_next = false;
             if (!h.hit) {                                             // Miss
@@ -129,12 +138,20 @@ __global__ __launch_bounds__(256) void k_render_fused(SceneDev sc, DispatchDev a
         }
         // RenderTarget[xy] = float4(color,1) -> R8G8B8A8_UNORM (hlsl:62)
         const uint32_t packed = unorm8(acc.x) | (unorm8(acc.y) << 8) | (unorm8(acc.z) << 16) | 0xff000000u;
-        const size_t o = a.tile_world == 1u ? (size_t)y * a.W + x
+        const size_t o = a.compact_out == 0u ? (size_t)y * a.W + x
                                             : (size_t)tile_local * (TILE * TILE) + py * TILE + px;
         a.out_rgba8[o] = packed;
         if (a.out_f32) a.out_f32[o] = make_float4(acc.x, acc.y, acc.z, 1.0f);
     }
 
+    if (DIAG) {
+        uint32_t mx = n_rays;
+        for (int off = 32; off > 0; off >>= 1) { uint32_t v = __shfl_xor(mx, off, 64); mx = v > mx ? v : mx; }
+        if (lane == 0) {
+            unsigned long long* d = a.diag + (size_t)(blockIdx.x * 4u + wave) * 4;
+            d[0] = diag_t0; d[1] = __builtin_amdgcn_s_memtime() - diag_t0; d[2] = mx; d[3] = diag_trips[wave];
+        }
+    }
     // ray count: one sharded add per wave
     uint32_t wr = wave_reduce_add(n_rays);
     if (lane == 0 && wr) atomicAdd(&a.ray_shards[(blockIdx.x * 4u + wave) & (RAY_SHARDS - 1)], wr);
@@ -147,6 +164,179 @@ __global__ __launch_bounds__(256) void k_render_fused(SceneDev sc, DispatchDev a
         v = wave_reduce_add(n_tir);   if (lane == 0 && v) atomicAdd(&a.counters[C_TIR], (unsigned long long)v);
         v = wave_reduce_add(cnt.nodes); if (lane == 0 && v) atomicAdd(&a.counters[C_NODES], (unsigned long long)v);
         v = wave_reduce_add(cnt.tris);  if (lane == 0 && v) atomicAdd(&a.counters[C_TRIS], (unsigned long long)v);
+        v = wave_reduce_add(valid ? 1u : 0u); if (lane == 0 && v) atomicAdd(&a.counters[C_PRIMARY], (unsigned long long)v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Lane-asynchronous form of the same renderer, for the reference's scene (one identity instance).
+//
+// k_render_fused keeps the 64 lanes of a wave in lock step: every lane traces "its" ray to the end,
+// then all lanes shade, then all trace the next ray -- so each step costs the slowest lane's
+// traversal (measured on monkey.obj: ~4x more loop trips than the longest lane needs).  Here every
+// lane runs its own pixel's depth-first ray tree as a little state machine (at an internal node /
+// holding a leaf / ray finished, waiting to be shaded) and the WAVE picks, each trip, the phase most
+// of its lanes are waiting for: internal-node step, triangle step or shading step.  Lanes never wait
+// for each other's rays; the expensive shading code runs when a majority needs it.  Arithmetic per
+// ray and the order of a pixel's leaves are unchanged, so results are bit-identical to k_render_fused.
+template <int STACK, int PEND, bool STATS>
+__global__ __launch_bounds__(256) void k_render_async(SceneDev sc, DispatchDev a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t* stk = lds + wave * (STACK * 64) + lane;
+
+    uint32_t tile_local, strip;
+    block_to_tile(blockIdx.x, tile_local, strip);
+    const uint32_t tile = tile_local * a.tile_world + a.tile_rank;
+    const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const uint32_t lx = compact1by1(lane), ly = compact1by1(lane >> 1);
+    const uint32_t px = wave * 8u + lx, py = strip * 8u + ly;
+    const uint32_t x = tx * TILE + px, y = ty * TILE + py;
+    const bool valid = tile_local < a.n_local_tiles && x < a.W && y < a.H;
+
+    uint32_t n_rays = 0, n_hits = 0, n_miss = 0, n_term = 0, n_tir = 0, n_nodes = 0, n_tris = 0;
+    uint32_t err = 0;
+    const float4* __restrict__ nodes = reinterpret_cast<const float4*>(sc.blas0.nodes);
+
+    // ---- per-lane state -------------------------------------------------------------------------
+    bool alive = valid;
+    f3 acc = mk3(0.0f, 0.0f, 0.0f);
+    PendRay pend[PEND];
+    int np = 0;
+    f3 O = mk3(a.cam[0], a.cam[1], a.cam[2]);                       // RayGen, RayTracing.hlsl:42-60
+    f3 D = valid ? camera_ray_dir(a.M, x, y, a.W, a.H) : mk3(1.0f, 0.0f, 0.0f);
+    float w = 1.0f;
+    uint32_t count = 0;
+    bool outside = true;
+    float tmin = a.tmin_p;
+    BoxRay br = box_ray(O, D);
+    HitRec h;
+    h.t = a.tmax_p; h.hit = false; h.prim = 0; h.leaf = 0; h.inst = 0; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f;
+    int node = 0, sp = 0;
+
+    for (;;) {
+        const bool wantI = alive && node >= 0;
+        const bool wantL = alive && node < 0 && node != TRAV_DONE;
+        const bool wantS = alive && node == TRAV_DONE;
+        const unsigned long long mI = __ballot(wantI), mL = __ballot(wantL), mS = __ballot(wantS);
+        if ((mI | mL | mS) == 0ull) break;
+        const int nI = __popcll(mI), nL = __popcll(mL), nS = __popcll(mS);
+        if (nI >= nL && nI >= nS) {
+            // ---- internal node step -----------------------------------------------------------------
+            if (wantI) {
+                const float4* q = nodes + (uint32_t)node * 4u;
+                const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                if (STATS) ++n_nodes;
+                float tn0, tn1;
+                const bool h0 = box_hit(br, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmin, h.t, tn0);
+                const bool h1 = box_hit(br, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmin, h.t, tn1);
+                const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+                if (h0 && h1) {
+                    const bool swap = tn1 < tn0;
+                    const int farc = swap ? c0 : c1;
+                    node = swap ? c1 : c0;
+                    if (sp < STACK) { stk[sp * 64] = (uint32_t)farc; ++sp; } else err = 1u;
+                } else if (h0 || h1) {
+                    node = h0 ? c0 : c1;
+                } else if (sp > 0) {
+                    --sp;
+                    node = (int)stk[sp * 64];
+                } else {
+                    node = TRAV_DONE;
+                }
+            }
+        } else if (nL >= nS) {
+            // ---- triangle step ------------------------------------------------------------------------
+            if (wantL) {
+                if (STATS) ++n_tris;
+                tri_test(sc.blas0.tris, (uint32_t)~node, O, D, tmin, outside ? CULL_BACK : CULL_FRONT, 0u, h);
+                if (sp > 0) { --sp; node = (int)stk[sp * 64]; } else node = TRAV_DONE;
+            }
+        } else {
+            // ---- shading step: Miss / ClosestHit for every lane whose ray is finished -------------------
+            if (wantS) {
+                ++n_rays;
+                bool have_next = false;
+                if (!h.hit) {                                             // Miss, hlsl:127-137
+                    if (STATS) ++n_miss;
+                    const f3 e = env_lookup(sc, D);
+                    acc.x = fmaf(w, e.x, acc.x); acc.y = fmaf(w, e.y, acc.y); acc.z = fmaf(w, e.z, acc.z);
+                } else {                                                  // ClosestHit, hlsl:79-125
+                    if (STATS) ++n_hits;
+                    if ((int)count < a.max_refract) {
+                        const f3 N = shading_normal<false>(sc, h);
+                        const f3 X = mk3(fmaf(h.t, D.x, O.x), fmaf(h.t, D.y, O.y), fmaf(h.t, D.z, O.z));
+                        const f3 Nf = outside ? N : neg3(N);
+                        const float R0 = (0.2f / 2.2f) * (0.2f / 2.2f);
+                        const float b = 1.0f - dot3(D, Nf);
+                        const float b2 = b * b, b4 = b2 * b2;
+                        const float R = (R0 * (1.0f - R0)) * (b4 * b);
+                        const float eta = outside ? a.inv_ior : a.ior;
+                        f3 d1;
+                        const bool refr = refract_ray(d1, D, Nf, eta);
+                        if (STATS && !refr) ++n_tir;
+                        const bool refl = (int)count < a.max_reflect;
+                        f3 d2 = mk3(0.0f, 0.0f, 0.0f);
+                        if (refl) d2 = normalize3(reflect_ray(D, Nf));
+                        const uint32_t c1 = count + 1u;
+                        O = X;
+                        if (refr) {
+                            if (refl) {
+                                PendRay p;
+                                p.ox = X.x; p.oy = X.y; p.oz = X.z; p.dx = d2.x; p.dy = d2.y; p.dz = d2.z;
+                                p.w = w * R; p.meta = c1 | (outside ? 0x10000u : 0u);
+#pragma unroll
+                                for (int k = 0; k < PEND; ++k) if (k == np) pend[k] = p;
+                                ++np;
+                            }
+                            D = d1; w = w * (1.0f - R); count = c1; outside = !outside;
+                            have_next = true;
+                        } else if (refl) {
+                            D = d2; w = w * R; count = c1;
+                            have_next = true;
+                        }
+                    } else if (STATS) {
+                        ++n_term;
+                    }
+                }
+                if (!have_next && np > 0) {
+                    --np;
+                    PendRay p = pend[0];
+#pragma unroll
+                    for (int k = 1; k < PEND; ++k) if (k == np) p = pend[k];
+                    O = mk3(p.ox, p.oy, p.oz); D = mk3(p.dx, p.dy, p.dz); w = p.w;
+                    count = p.meta & 0xffffu; outside = (p.meta & 0x10000u) != 0u;
+                    have_next = true;
+                }
+                if (have_next) {                                          // TraceRay(child, [1e-3, 1000])
+                    tmin = a.tmin_s;
+                    br = box_ray(O, D);
+                    h.t = a.tmax_s; h.hit = false; h.prim = 0; h.leaf = 0; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f;
+                    node = 0; sp = 0;
+                } else {                                                  // RenderTarget[xy] = float4(color,1)
+                    const uint32_t packed = unorm8(acc.x) | (unorm8(acc.y) << 8) | (unorm8(acc.z) << 16) | 0xff000000u;
+                    const size_t o = a.compact_out == 0u ? (size_t)y * a.W + x
+                                                         : (size_t)tile_local * (TILE * TILE) + py * TILE + px;
+                    a.out_rgba8[o] = packed;
+                    if (a.out_f32) a.out_f32[o] = make_float4(acc.x, acc.y, acc.z, 1.0f);
+                    alive = false;
+                }
+            }
+        }
+    }
+
+    uint32_t wr = wave_reduce_add(n_rays);
+    if (lane == 0 && wr) atomicAdd(&a.ray_shards[(blockIdx.x * 4u + wave) & (RAY_SHARDS - 1)], wr);
+    if (err) atomicOr(a.error_flag, 1u);
+    if (STATS) {
+        uint32_t v;
+        v = wave_reduce_add(n_hits);  if (lane == 0 && v) atomicAdd(&a.counters[C_HITS], (unsigned long long)v);
+        v = wave_reduce_add(n_miss);  if (lane == 0 && v) atomicAdd(&a.counters[C_MISSES], (unsigned long long)v);
+        v = wave_reduce_add(n_term);  if (lane == 0 && v) atomicAdd(&a.counters[C_TERMINAL], (unsigned long long)v);
+        v = wave_reduce_add(n_tir);   if (lane == 0 && v) atomicAdd(&a.counters[C_TIR], (unsigned long long)v);
+        v = wave_reduce_add(n_nodes); if (lane == 0 && v) atomicAdd(&a.counters[C_NODES], (unsigned long long)v);
+        v = wave_reduce_add(n_tris);  if (lane == 0 && v) atomicAdd(&a.counters[C_TRIS], (unsigned long long)v);
         v = wave_reduce_add(valid ? 1u : 0u); if (lane == 0 && v) atomicAdd(&a.counters[C_PRIMARY], (unsigned long long)v);
     }
 }
@@ -192,6 +382,21 @@ __global__ __launch_bounds__(256) void k_assemble_tiles(const uint32_t* __restri
         frame[(size_t)y * W + x] = gathered[((size_t)rank * max_tiles + tile_local) * (TILE * TILE) + py * TILE + px];
 }
 
+__global__ __launch_bounds__(256) void k_assemble_frames(const uint32_t* __restrict__ gathered, uint32_t* __restrict__ frames,
+                                                         uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles,
+                                                         uint32_t world, size_t rank_stride, size_t frame_stride,
+                                                         size_t out_stride)
+{
+    const uint32_t tile = blockIdx.x >> 2, strip = blockIdx.x & 3u, f = blockIdx.y;
+    if (tile >= n_tiles) return;
+    const uint32_t rank = tile % world, tile_local = tile / world;
+    const uint32_t px = threadIdx.x & 31u, py = strip * 8u + (threadIdx.x >> 5);
+    const uint32_t x = (tile % tiles_x) * TILE + px, y = (tile / tiles_x) * TILE + py;
+    if (x < W && y < H)
+        frames[f * out_stride + (size_t)y * W + x] =
+            gathered[rank * rank_stride + f * frame_stride + (size_t)tile_local * (TILE * TILE) + py * TILE + px];
+}
+
 // ------------------------------------------------------------------------------------ launchers
 template <int STACK, int PEND, bool TLAS>
 static hipError_t launch_fused_spt(const SceneDev& sc, const DispatchDev& a, bool stats, hipStream_t s)
@@ -203,15 +408,37 @@ static hipError_t launch_fused_spt(const SceneDev& sc, const DispatchDev& a, boo
 }
 
 template <int STACK, int PEND>
+static hipError_t launch_async_sp(const SceneDev& sc, const DispatchDev& a, bool stats, hipStream_t s)
+{
+    const size_t lds = (size_t)4 * STACK * 64 * sizeof(uint32_t);
+    if (stats) hipLaunchKernelGGL((k_render_async<STACK, PEND, true>), dim3(a.n_blocks), dim3(256), lds, s, sc, a);
+    else       hipLaunchKernelGGL((k_render_async<STACK, PEND, false>), dim3(a.n_blocks), dim3(256), lds, s, sc, a);
+    return hipGetLastError();
+}
+
+static bool use_sync_kernel()
+{
+    static const bool v = [] { const char* e = getenv("RR_DEBUG_KERNEL"); return e && !strcmp(e, "sync"); }();
+    return v;
+}
+
+template <int STACK, int PEND>
 static hipError_t launch_fused_sp(const SceneDev& sc, const DispatchDev& a, bool stats, hipStream_t s)
 {
-    return sc.single_identity ? launch_fused_spt<STACK, PEND, false>(sc, a, stats, s)
-                              : launch_fused_spt<STACK, PEND, true>(sc, a, stats, s);
+    if (!sc.single_identity) return launch_fused_spt<STACK, PEND, true>(sc, a, stats, s);
+    if (use_sync_kernel()) return launch_fused_spt<STACK, PEND, false>(sc, a, stats, s);
+    return launch_async_sp<STACK, PEND>(sc, a, stats, s);
 }
 
 hipError_t launch_render_fused(const SceneDev& sc, const DispatchDev& a, int stack, int pend, bool stats, hipStream_t s)
 {
     if (a.n_blocks == 0) return hipSuccess;
+    if (a.diag) {       // diagnostic build of the reference-scene kernel (never used by the product path)
+        hipLaunchKernelGGL((k_render_fused<32, 2, false, false, true>), dim3(a.n_blocks), dim3(256), 4 * 32 * 64 * 4, s, sc, a);
+        return hipGetLastError();
+    }
+    if (stack <= 16 && pend <= 2) return launch_fused_sp<16, 2>(sc, a, stats, s);
+    if (stack <= 24 && pend <= 2) return launch_fused_sp<24, 2>(sc, a, stats, s);
     if (stack <= 32) return pend <= 2 ? launch_fused_sp<32, 2>(sc, a, stats, s) : launch_fused_sp<32, 8>(sc, a, stats, s);
     return pend <= 2 ? launch_fused_sp<64, 2>(sc, a, stats, s) : launch_fused_sp<64, 8>(sc, a, stats, s);
 }
@@ -237,6 +464,16 @@ hipError_t launch_assemble_tiles(const uint32_t* gathered, uint32_t* frame, uint
     if (n_tiles == 0) return hipSuccess;
     hipLaunchKernelGGL(k_assemble_tiles, dim3(n_tiles * 4u), dim3(256), 0, s, gathered, frame, W, H, tiles_x, n_tiles, world,
                        max_tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble_frames(const uint32_t* gathered, uint32_t* frames, uint32_t W, uint32_t H, uint32_t tiles_x,
+                                  uint32_t n_tiles, uint32_t world, size_t rank_stride, size_t frame_stride,
+                                  size_t out_stride, uint32_t n_frames, hipStream_t s)
+{
+    if (n_tiles == 0 || n_frames == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_assemble_frames, dim3(n_tiles * 4u, n_frames), dim3(256), 0, s, gathered, frames, W, H, tiles_x,
+                       n_tiles, world, rank_stride, frame_stride, out_stride);
     return hipGetLastError();
 }
 

@@ -68,7 +68,9 @@ struct DispatchDev {
     uint32_t W, H;
     uint32_t tiles_x, n_tiles;      // 32x32 tiles over the frame
     uint32_t tile_rank, tile_world;
-    uint32_t n_blocks;              // 4 blocks (32x8 strips) per local tile
+    uint32_t n_local_tiles;         // tiles this rank renders
+    uint32_t n_blocks;              // 4 blocks (32x8 strips) per local tile, tiles rounded up to a multiple of 8
+    uint32_t compact_out;           // 0: W*H raster; 1: [local tile][32*32] (sharded frames)
     int32_t max_refract, max_reflect;
     float ior, inv_ior;
     float tmin_p, tmax_p, tmin_s, tmax_s;
@@ -77,6 +79,7 @@ struct DispatchDev {
     unsigned long long* counters;   // rr::Counter slots
     uint32_t* ray_shards;           // RAY_SHARDS u32 partial ray counts
     uint32_t* error_flag;
+    unsigned long long* diag;       // diagnostic builds only: 4 x u64 per wave {start, cycles, rays(max lane), loop trips}
 };
 
 enum Counter : int {

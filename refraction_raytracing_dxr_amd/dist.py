@@ -76,3 +76,97 @@ def assemble_host(gathered, width, height, world):
         w, h = min(TILE, width - x0), min(TILE, height - y0)
         frame[y0:y0 + h, x0:x0 + w] = g[t % world, t // world, :h, :w]
     return frame
+
+
+class ShardedFrames:
+    """Throughput path for N > 1: F frames per collective ("fewer, larger collectives"), two buffer
+    sets so that the gather of batch b runs on RCCL's stream while batch b+1 renders.
+
+    Per batch and rank: F launches of the render kernel writing this rank's tiles straight into the
+    send buffer (rr_render_orbit_sharded), one gather to rank 0 (F * max_tiles * 4 KiB per rank),
+    and on rank 0 one de-interleave launch for the F frames of the previous batch.
+    """
+
+    RING = 2
+
+    def __init__(self, renderer, width, height, rank, world, device, frames_per_gather=8):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.r = renderer
+        self.width, self.height, self.rank, self.world = width, height, rank, world
+        self.F = int(frames_per_gather)
+        self.max_tiles = max_local_tiles(width, height, world)
+        self.frame_bytes = self.max_tiles * TILE_BYTES
+        renderer.set_tile_partition(rank, world)
+        self.send = [torch.zeros(self.F * self.frame_bytes, dtype=torch.uint8, device=device) for _ in range(self.RING)]
+        self.recv = [torch.zeros(world * self.F * self.frame_bytes, dtype=torch.uint8, device=device)
+                     for _ in range(self.RING)] if rank == 0 else None
+        # the most recent batch of assembled frames (rank 0)
+        self.frames = torch.zeros(self.F * height * width * 4, dtype=torch.uint8, device=device) if rank == 0 else None
+        self.last_batch = 0
+        self._via_host = world > 1 and dist.get_backend() == "gloo"     # test rigs without RCCL: stage through host
+
+    def _gather(self, slot, nf):
+        n = nf * self.frame_bytes
+        send = self.send[slot][:n]
+        if self.world == 1:
+            self.recv[slot][:n].copy_(send)
+            return None
+        chunks = None
+        if self.rank == 0:
+            chunks = [self.recv[slot][r * self.F * self.frame_bytes: r * self.F * self.frame_bytes + n]
+                      for r in range(self.world)]
+        if self._via_host:
+            hs = send.cpu()
+            hc = [self.torch.empty_like(hs) for _ in range(self.world)] if self.rank == 0 else None
+            self.dist.gather(hs, hc, dst=0)
+            if self.rank == 0:
+                for c, h in zip(chunks, hc):
+                    c.copy_(h)
+            return None
+        return self.dist.gather(send, chunks, dst=0, async_op=True)
+
+    def _finish(self, pending):
+        slot, nf, work = pending
+        if work is not None:
+            work.wait()                     # current stream waits for RCCL's stream; the host does not
+        if self.rank == 0:
+            self.r.assemble_frames(self.recv[slot].data_ptr(), self.world, self.F * self.frame_bytes, self.frame_bytes,
+                                   nf, self.width, self.height, self.frames.data_ptr(), self.height * self.width * 4)
+            self.last_batch = nf
+
+    def render_orbit(self, n_frames, angle=0.01, angle_step=0.01, params=None):
+        """Renders, gathers and assembles n_frames; returns the rays this rank traced (blocks at the end
+        to read the counter)."""
+        from .host import default_params
+        from ._capi import DISPATCH_KEEP_COUNTERS
+        base = params if params is not None else default_params()
+        pending = None
+        done = 0
+        b = 0
+        while done < n_frames:
+            nf = min(self.F, n_frames - done)
+            slot = b % self.RING
+            p = default_params()
+            for f, _ in base._fields_:
+                setattr(p, f, getattr(base, f))
+            if done > 0:
+                p.flags |= DISPATCH_KEEP_COUNTERS
+            angle = self.r.render_orbit_sharded(self.width, self.height, nf, self.send[slot].data_ptr(), self.frame_bytes,
+                                                angle=angle, angle_step=angle_step, params=p)
+            work = self._gather(slot, nf)
+            if pending is not None:
+                self._finish(pending)
+            pending = (slot, nf, work)
+            done += nf
+            b += 1
+        if pending is not None:
+            self._finish(pending)
+        return self.r.stats().rays
+
+    def frames_host(self):
+        """rank 0: the last batch as uint8 [n, h, w, 4]"""
+        assert self.rank == 0
+        self.torch.cuda.synchronize()
+        return self.frames.view(self.F, self.height, self.width, 4)[:self.last_batch].cpu().numpy()

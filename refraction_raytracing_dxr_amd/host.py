@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import (DISPATCH_COLLECT_STATS, DISPATCH_FLOAT_OUTPUT, HIT_DTYPE, INSTANCE_DTYPE, NODE_DTYPE, RAY_DTYPE,
+from ._capi import (DISPATCH_COLLECT_STATS, DISPATCH_FLOAT_OUTPUT, DISPATCH_KEEP_COUNTERS, DISPATCH_TIME_KERNEL, HIT_DTYPE, INSTANCE_DTYPE, NODE_DTYPE, RAY_DTYPE,
                     TRI_DTYPE, VERTEX_DTYPE, DispatchParams, RRError, SceneConstants, Stats)
 
 FOV_Y = float(np.float32(52.0 / 180.0 * 3.1415))     # RefractionDemo.cpp:559
@@ -203,6 +203,47 @@ class Renderer:
     def assemble_tiles(self, gathered_ptr, world, frame_ptr=None):
         self._ck(self._L.rr_assemble_tiles(self._h, C.c_void_p(gathered_ptr), world,
                                            C.c_void_p(frame_ptr) if frame_ptr else None), "rr_assemble_tiles")
+
+    def render_orbit(self, width, height, n_frames, angle=0.01, angle_step=0.01, params=None, fov_y=FOV_Y,
+                     aspect=ASPECT, zn=1.0, zf=125.0):
+        """n_frames of the drawFrame loop (camera -> DispatchRays -> angle += step), asynchronous.
+        Returns the angle the next frame would use."""
+        p = params if params is not None else default_params()
+        a = C.c_float(float(np.float32(angle)))
+        self._ck(self._L.rr_render_orbit(self._h, width, height, C.byref(p), C.byref(a), float(np.float32(angle_step)),
+                                         n_frames, fov_y, aspect, zn, zf), "rr_render_orbit")
+        self.width, self.height = width, height
+        return a.value
+
+    def render_orbit_sharded(self, width, height, n_frames, tiles_ptr, frame_stride_bytes, angle=0.01,
+                             angle_step=0.01, params=None, fov_y=FOV_Y, aspect=ASPECT, zn=1.0, zf=125.0):
+        p = params if params is not None else default_params()
+        a = C.c_float(float(np.float32(angle)))
+        self._ck(self._L.rr_render_orbit_sharded(self._h, width, height, C.byref(p), C.byref(a),
+                                                 float(np.float32(angle_step)), n_frames, fov_y, aspect, zn, zf,
+                                                 C.c_void_p(tiles_ptr), frame_stride_bytes), "rr_render_orbit_sharded")
+        self.width, self.height = width, height
+        return a.value
+
+    def assemble_frames(self, gathered_ptr, world, rank_stride_bytes, frame_stride_bytes, n_frames, width, height,
+                        frames_ptr, out_stride_bytes):
+        self._ck(self._L.rr_assemble_frames(self._h, C.c_void_p(gathered_ptr), world, rank_stride_bytes,
+                                            frame_stride_bytes, n_frames, width, height, C.c_void_p(frames_ptr),
+                                            out_stride_bytes), "rr_assemble_frames")
+
+    def timing_begin(self):
+        self._ck(self._L.rr_timing_begin(self._h), "rr_timing_begin")
+
+    def timing_end(self):
+        ms = C.c_float()
+        self._ck(self._L.rr_timing_end(self._h, C.byref(ms)), "rr_timing_end")
+        return ms.value
+
+    def kernel_time(self):
+        """-> (sum of render-kernel milliseconds, launches) of the dispatches flagged DISPATCH_TIME_KERNEL"""
+        ms, n = C.c_float(), C.c_uint32()
+        self._ck(self._L.rr_kernel_time(self._h, C.byref(ms), C.byref(n)), "rr_kernel_time")
+        return ms.value, n.value
 
     def stats(self):
         st = Stats()
