@@ -3,7 +3,9 @@
 
 A step = one frame of the reference's drawFrame loop: camera constants for the orbit angle,
 DispatchRays over the whole 1920x1080 frame, (N > 1: RCCL gather of the image tiles + de-interleave
-on rank 0).  Workload = BASELINE.json configs[2] (the configuration the metric is quoted on):
+on rank 0).  Frames are issued --frames-per-dispatch at a time as the depth slices of one
+DispatchRays(W,H,Depth) launch (every frame is fully rendered into its own buffer; Depth 1, the
+reference's shape, is reported next to it as depth1_kernel_us).  Workload = BASELINE.json configs[2] (the configuration the metric is quoted on):
 monkey.obj (967 triangles, the reference's own file), 8 refraction bounces, 2 reflection bounces,
 seeded procedural 2048x1024 HDR env map (the reference's envmap.hdr is missing from the mount),
 frame k uses angle 0.01*(k+1) like the reference's `angle += 0.01f`.
@@ -43,12 +45,24 @@ def survey_formula_bytes(st):
             + 16 * st.pixels)
 
 
+def host_cores():
+    """threads the CPU baseline may really use: cgroup quota if there is one, else the affinity mask"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(mesh, env, budget_s=15.0):
     """The CPU oracle (oracle/, C, fp32, median-split BVH, one pthread per host core) timed on a
     bounded sample of the same workload: whole 1920x1080 frames of the same orbit."""
     import oracle as O
     import refraction_raytracing_dxr_amd as rr
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     s = O.Scene()
     s.add_mesh(mesh.verts, mesh.indices)
     s.set_envmap(env)
@@ -74,7 +88,8 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--frames-per-gather", type=int, default=8)
+    ap.add_argument("--frames-per-dispatch", type=int, default=16,
+                    help="depth slices per launch (DispatchRays(W,H,Depth)); N>1: also frames per RCCL gather")
     args = ap.parse_args()
 
     import torch
@@ -111,13 +126,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    F = max(1, args.frames_per_dispatch)
     if world == 1:
         r.set_tile_partition(0, 1)
-        r.render_orbit(W, H, Wm, angle=0.01, params=params)                 # warmup, untimed
+        r.render_orbit(W, H, Wm, angle=0.01, params=params, frames_per_dispatch=F)      # warmup, untimed
         barrier()
         t0 = time.perf_counter()
         r.timing_begin()
-        r.render_orbit(W, H, K, angle=0.01, params=params)                  # EXACTLY K timed steps
+        r.render_orbit(W, H, K, angle=0.01, params=params, frames_per_dispatch=F)       # EXACTLY K timed steps (frames)
         region_ms = r.timing_end()
         barrier()
         elapsed = time.perf_counter() - t0
@@ -125,7 +141,7 @@ def main():
         total_rays = st.rays
         overflow = st.traversal_overflow
     else:
-        sf = rr.dist.ShardedFrames(r, W, H, rank, world, torch.device("cuda", local_rank), args.frames_per_gather)
+        sf = rr.dist.ShardedFrames(r, W, H, rank, world, torch.device("cuda", local_rank), args.frames_per_dispatch)
         sf.render_orbit(Wm, angle=0.01, params=params)
         barrier()
         t0 = time.perf_counter()
@@ -146,15 +162,19 @@ def main():
     cpu = None
     if rank == 0:
         r.set_tile_partition(0, 1)
-        n_prof = min(K, 200)
-        r.render_orbit(W, H, n_prof, angle=0.01, params=rr.default_params(
+        n_prof = max(F, (min(K, 256) // F) * F)                              # whole launches of F slices
+        r.render_orbit(W, H, n_prof, angle=0.01, frames_per_dispatch=F, params=rr.default_params(
             max_refract=MAX_REFRACT, max_reflect=MAX_REFLECT, flags=rr.DISPATCH_COLLECT_STATS))
         sst = r.stats()                                                     # exact counters, summed over n_prof frames
-        r.render_orbit(W, H, n_prof, angle=0.01, params=rr.default_params(
+        r.render_orbit(W, H, n_prof, angle=0.01, frames_per_dispatch=F, params=rr.default_params(
             max_refract=MAX_REFRACT, max_reflect=MAX_REFLECT, flags=rr.DISPATCH_TIME_KERNEL))
         kms, kn = r.kernel_time()                                           # HIP events around each launch, on the launch stream
-        bytes_per_launch = algorithmic_bytes(sst) / n_prof
+        bytes_per_launch = algorithmic_bytes(sst) / kn                      # one launch = F frames
         kernel_us = kms / kn * 1e3
+        # the reference's own shape, one DispatchRays per frame (Depth 1), for comparison
+        r.render_orbit(W, H, 32, angle=0.01, frames_per_dispatch=1, params=rr.default_params(
+            max_refract=MAX_REFRACT, max_reflect=MAX_REFLECT, flags=rr.DISPATCH_TIME_KERNEL))
+        k1ms, k1n = r.kernel_time()
         achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -165,13 +185,14 @@ def main():
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "kernel": "k_render_fused", "kernel_us": round(kernel_us, 2),
+                    "kernel": "k_render_fused", "kernel_us": round(kernel_us, 2), "frames_per_launch": F,
+                    "depth1_kernel_us": round(k1ms / k1n * 1e3, 2),
                     "algorithmic_bytes_per_launch": int(bytes_per_launch),
                     "bytes_per_ray": round(algorithmic_bytes(sst) / sst.rays, 1),
                     "survey_formula_bytes_per_ray": round(survey_formula_bytes(sst) / sst.rays, 1),
                     "node_visits_per_ray": round(sst.node_visits / sst.rays, 2),
                     "tri_tests_per_ray": round(sst.tri_tests / sst.rays, 2),
-                    "kernel_grays_per_s": round(sst.rays / n_prof / (kernel_us * 1e-6) / 1e9, 3)}
+                    "kernel_grays_per_s": round(sst.rays / kn / (kernel_us * 1e-6) / 1e9, 3)}
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(mesh, env)
 
@@ -194,7 +215,7 @@ def main():
                                    "orbit angle 0.01*(k+1), seeded procedural 2048x1024 RGB32F env map",
                        "rays_per_frame": round(total_rays / K, 1),
                        "parallelism": "tiles32x32-roundrobin-x%d" % world,
-                       "frames_per_gather": args.frames_per_gather if world > 1 else None},
+                       "frames_per_dispatch": F},
             "device_region_ms_per_step": round(region_ms / K, 5) if region_ms is not None else None,
             "roofline": roofline,
             "cpu_baseline": cpu,

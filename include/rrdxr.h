@@ -148,10 +148,17 @@ int  rr_set_camera(rr_context* ctx, const rr_scene_constants* constants);
 int  rr_set_tile_partition(rr_context* ctx, uint32_t rank, uint32_t world);
 /* DispatchRays(desc{W,H,1}), RefractionDemo.cpp:580-594.  Asynchronous on the stream. */
 int  rr_dispatch_rays(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispatch_params* params);
+/* DispatchRays(desc{W,H,Depth}): the reference always passes Depth = 1 (RefractionDemo.cpp:591); here
+ * depth slice f is a whole frame rendered with constants[f] (the constant buffer becomes an array).
+ * One launch renders all slices, so the long-running waves of one frame overlap the next frame's work.
+ * Slice f is read back with rr_read_frame_slice(ctx, f, ...). */
+int  rr_dispatch_rays_batch(rr_context* ctx, uint32_t width, uint32_t height, uint32_t depth,
+                            const rr_scene_constants* constants, const rr_dispatch_params* params);
 /* CopyResource(backbuffer <- rtTexture) + Present, RefractionDemo.cpp:596-609: blocks, copies the
  * R8G8B8A8_UNORM frame (and the float4 frame if RR_DISPATCH_FLOAT_OUTPUT was set) to host memory.
  * Either pointer may be NULL.  Only valid with world == 1. */
 int  rr_read_frame(rr_context* ctx, uint8_t* rgba8, float* rgba32f);
+int  rr_read_frame_slice(rr_context* ctx, uint32_t slice, uint8_t* rgba8, float* rgba32f);
 
 /* Sharded output.  A context with world > 1 renders into a compact tile buffer:
  * rr_local_tile_count tiles of 32*32 RGBA8 pixels (4096 B each), tile-major. */
@@ -165,18 +172,21 @@ int  rr_export_tiles(rr_context* ctx, void* d_dst);
 int  rr_assemble_tiles(rr_context* ctx, const void* d_gathered, uint32_t world, void* d_frame);
 
 /* drawFrame loop in C (RefractionDemo.cpp:557-567 + WinMain.cpp:49-59): n_frames times
- * { camera constants for `angle`; rr_set_camera; rr_dispatch_rays; angle += angle_step }.
+ * { camera constants for `angle`; rr_set_camera; rr_dispatch_rays; angle += angle_step }, issued
+ * as ceil(n_frames / frames_per_dispatch) launches of frames_per_dispatch depth slices each
+ * (1 = the reference's one DispatchRays per frame).  The last frames_per_dispatch frames stay
+ * readable through rr_read_frame_slice.
  * Asynchronous; *angle is advanced like the reference's `static float angle`.  The counters
  * of rr_get_stats accumulate over the n_frames (they are zeroed once, before the first). */
 int  rr_render_orbit(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispatch_params* params,
-                     float* angle, float angle_step, uint32_t n_frames,
+                     float* angle, float angle_step, uint32_t n_frames, uint32_t frames_per_dispatch,
                      float fov_y, float aspect, float zn, float zf);
 
 /* The same loop for a sharded context (rr_set_tile_partition; world == 1 is allowed): frame f renders this rank's tiles straight into
  * caller device memory at d_tiles + f*frame_stride_bytes (max_tiles_any_rank*4096 B each, tail
  * zero-filled), i.e. into the send buffer of the RCCL gather, with no intermediate copy. */
 int  rr_render_orbit_sharded(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispatch_params* params,
-                             float* angle, float angle_step, uint32_t n_frames,
+                             float* angle, float angle_step, uint32_t n_frames, uint32_t frames_per_dispatch,
                              float fov_y, float aspect, float zn, float zf,
                              void* d_tiles, uint64_t frame_stride_bytes);
 /* rank 0, after gathering n_frames at once: frame f of rank r lies at

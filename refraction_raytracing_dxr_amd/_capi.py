@@ -68,16 +68,18 @@ SYMBOLS = {
     "rr_set_camera": (C.c_int, [_P, C.POINTER(SceneConstants)]),
     "rr_set_tile_partition": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "rr_dispatch_rays": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(DispatchParams)]),
+    "rr_dispatch_rays_batch": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.POINTER(DispatchParams)]),
     "rr_read_frame": (C.c_int, [_P, _P, _P]),
+    "rr_read_frame_slice": (C.c_int, [_P, C.c_uint32, _P, _P]),
     "rr_local_tile_count": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rr_export_tiles": (C.c_int, [_P, _P]),
     "rr_assemble_tiles": (C.c_int, [_P, _P, C.c_uint32, _P]),
     "rr_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "rr_render_orbit": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(DispatchParams), C.POINTER(C.c_float),
-                                  C.c_float, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float]),
+                                  C.c_float, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float]),
     "rr_render_orbit_sharded": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(DispatchParams), C.POINTER(C.c_float),
-                                          C.c_float, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float, _P,
-                                          C.c_uint64]),
+                                          C.c_float, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float,
+                                          _P, C.c_uint64]),
     "rr_assemble_frames": (C.c_int, [_P, _P, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                      _P, C.c_uint64]),
     "rr_timing_begin": (C.c_int, [_P]),

@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -54,6 +55,7 @@ struct CounterBlock {
 
 struct rr_context {
     int device = 0;
+    int n_cus = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
@@ -73,16 +75,19 @@ struct rr_context {
 
     rr_scene_constants cam;
     bool cam_set = false;
+    CamDev* d_cams = nullptr;        // device-side constant buffer(s), one per depth slice
+    size_t cams_cap = 0;
+
     uint32_t tile_rank = 0, tile_world = 1;
 
     // frame
-    uint32_t W = 0, H = 0, frame_world = 0;
+    uint32_t W = 0, H = 0, frame_world = 0, frame_depth = 1;
     uint32_t* d_rgba8 = nullptr;     // world==1: W*H; else local tiles
     float4*   d_f32 = nullptr;
     uint32_t* d_assembled = nullptr; // rank-0 raster after rr_assemble_tiles
     size_t    rgba_elems = 0, f32_elems = 0, assembled_elems = 0;
     bool      have_f32 = false, have_frame = false, have_assembled = false;
-    uint32_t  last_pixels = 0;
+    uint64_t  last_pixels = 0;
     uint64_t  accum_pixels = 0;      // pixels of all dispatches since the counters were last zeroed
     bool      last_stats = false;
 
@@ -92,8 +97,6 @@ struct rr_context {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> kev;     // pairs
     uint32_t kev_used = 0;
-    bool accumulate_counters = false;
-    uint32_t* ext_tiles = nullptr;   // rr_render_orbit_sharded: render straight into caller memory
 
     // trace_rays scratch
     rr_ray_dev* d_rays = nullptr;
@@ -248,6 +251,7 @@ int rr_create(int device_ordinal, rr_context** out)
     rr_context* ctx = new (std::nothrow) rr_context();
     if (!ctx) return RR_ERR_OUT_OF_MEMORY;
     ctx->device = device_ordinal;
+    ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipSetDevice(device_ordinal) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc(&ctx->d_cnt, sizeof(CounterBlock)) != hipSuccess) {
@@ -268,7 +272,7 @@ int rr_destroy(rr_context* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (MeshRes& m : ctx->meshes) { dfree(m.d_verts); dfree(m.d_idx); dfree(m.nodes); dfree(m.tris); dfree(m.nrms); }
     dfree(ctx->d_env); dfree(ctx->d_insts); dfree(ctx->d_tlas); dfree(ctx->d_rgba8); dfree(ctx->d_f32);
-    dfree(ctx->d_assembled); dfree(ctx->d_cnt); dfree(ctx->d_rays); dfree(ctx->d_hits);
+    dfree(ctx->d_assembled); dfree(ctx->d_cnt); dfree(ctx->d_rays); dfree(ctx->d_hits); dfree(ctx->d_cams);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
@@ -477,54 +481,75 @@ int rr_local_tile_count(rr_context* ctx, uint32_t width, uint32_t height, uint32
     return RR_OK;
 }
 
-int rr_dispatch_rays(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispatch_params* params)
+namespace {
+
+int ensure_cams(rr_context* ctx, size_t n)
 {
-    if (int r = use_device(ctx)) return r;
-    if (width == 0 || height == 0 || width > 32768 || height > 32768)
-        return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_dispatch_rays: bad frame size");
-    if (!ctx->tlas_built) return fail(ctx, RR_ERR_STATE, "rr_dispatch_rays: build the BLAS and TLAS first");
-    if (!ctx->cam_set) return fail(ctx, RR_ERR_STATE, "rr_dispatch_rays: rr_set_camera first");
-    rr_dispatch_params p;
-    if (params) p = *params; else rr_default_dispatch_params(&p);
+    if (n <= ctx->cams_cap) return RR_OK;
+    RR_HIP(hipStreamSynchronize(ctx->stream));
+    dfree(ctx->d_cams);
+    ctx->cams_cap = 0;
+    size_t cap = n < 64 ? 64 : n;
+    RR_HIP(hipMalloc(&ctx->d_cams, cap * sizeof(CamDev)));
+    ctx->cams_cap = cap;
+    return RR_OK;
+}
+
+// DispatchRays(W, H, depth): slice f uses the constants d_cams[f] and writes to out + f*stride.
+// ext_tiles != null: compact tile output into caller memory with the given stride (sharded frames).
+int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t depth, const CamDev* d_cams,
+                  const rr_dispatch_params& p, uint32_t* ext_tiles, size_t ext_stride_elems, bool keep_counters)
+{
+    if (width == 0 || height == 0 || width > 32768 || height > 32768 || depth == 0 || depth > 65535)
+        return fail(ctx, RR_ERR_INVALID_ARGUMENT, "dispatch: bad frame size or depth");
+    if (!ctx->tlas_built) return fail(ctx, RR_ERR_STATE, "dispatch: build the BLAS and TLAS first");
     if (p.max_refract < 0 || p.max_refract > 65535 || p.max_reflect < 0)
-        return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_dispatch_rays: negative bounce limit");
-    if (p.max_reflect > 8) return fail(ctx, RR_ERR_UNSUPPORTED, "rr_dispatch_rays: max_reflect > 8 (parked-ray registers)");
-    if (!(p.ior > 0.0f)) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_dispatch_rays: ior must be > 0");
+        return fail(ctx, RR_ERR_INVALID_ARGUMENT, "dispatch: negative bounce limit");
+    if (p.max_reflect > 8) return fail(ctx, RR_ERR_UNSUPPORTED, "dispatch: max_reflect > 8 (parked-ray registers)");
+    if (!(p.ior > 0.0f)) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "dispatch: ior must be > 0");
 
     uint32_t tiles_x, n_tiles, local, max_local;
     tile_counts(width, height, ctx->tile_rank, ctx->tile_world, tiles_x, n_tiles, local, max_local);
     const bool want_f32 = (p.flags & RR_DISPATCH_FLOAT_OUTPUT) != 0;
-    const size_t elems = ctx->tile_world == 1 ? (size_t)width * height : (size_t)max_local * TILE * TILE;
-    if (elems > ctx->rgba_elems || !ctx->d_rgba8) {
-        RR_HIP(hipStreamSynchronize(ctx->stream));
-        dfree(ctx->d_rgba8);
-        ctx->rgba_elems = 0;
-        RR_HIP(hipMalloc(&ctx->d_rgba8, elems * 4));
-        ctx->rgba_elems = elems;
-    }
-    if (want_f32 && (elems > ctx->f32_elems || !ctx->d_f32)) {
-        RR_HIP(hipStreamSynchronize(ctx->stream));
-        dfree(ctx->d_f32);
-        ctx->f32_elems = 0;
-        RR_HIP(hipMalloc(&ctx->d_f32, elems * 16));
-        ctx->f32_elems = elems;
+    const bool compact = ctx->tile_world > 1 || ext_tiles != nullptr;
+    const size_t slice_elems = compact ? (size_t)max_local * TILE * TILE : (size_t)width * height;
+    const size_t stride = ext_tiles ? ext_stride_elems : slice_elems;
+    if (ext_tiles && want_f32) return fail(ctx, RR_ERR_UNSUPPORTED, "dispatch: float output is not available for external tile buffers");
+    if (!ext_tiles) {
+        const size_t elems = slice_elems * depth;
+        if (elems > ctx->rgba_elems || !ctx->d_rgba8) {
+            RR_HIP(hipStreamSynchronize(ctx->stream));
+            dfree(ctx->d_rgba8);
+            ctx->rgba_elems = 0;
+            RR_HIP(hipMalloc(&ctx->d_rgba8, elems * 4));
+            ctx->rgba_elems = elems;
+        }
+        if (want_f32 && (elems > ctx->f32_elems || !ctx->d_f32)) {
+            RR_HIP(hipStreamSynchronize(ctx->stream));
+            dfree(ctx->d_f32);
+            ctx->f32_elems = 0;
+            RR_HIP(hipMalloc(&ctx->d_f32, elems * 16));
+            ctx->f32_elems = elems;
+        }
     }
 
     SceneDev sc;
     fill_scene(ctx, sc);
     DispatchDev a;
     memset(&a, 0, sizeof a);
-    memcpy(a.M, ctx->cam.proj_inv, 64);
-    memcpy(a.cam, ctx->cam.camera_loc, 16);
+    a.cams = d_cams;
+    a.n_frames = depth;
+    a.blocks_per_frame = ((local + 7u) & ~7u) * 4u;
+    a.frame_stride = stride;
     a.W = width; a.H = height; a.tiles_x = tiles_x; a.n_tiles = n_tiles;
     a.tile_rank = ctx->tile_rank; a.tile_world = ctx->tile_world;
     a.n_local_tiles = local;
-    a.n_blocks = ((local + 7u) & ~7u) * 4u;
-    a.compact_out = (ctx->tile_world > 1 || ctx->ext_tiles) ? 1u : 0u;
+    a.n_blocks = a.blocks_per_frame * depth;
+    a.compact_out = compact ? 1u : 0u;
     a.max_refract = p.max_refract; a.max_reflect = p.max_reflect;
     a.ior = p.ior; a.inv_ior = 1.0f / p.ior;
     a.tmin_p = p.tmin_primary; a.tmax_p = p.tmax_primary; a.tmin_s = p.tmin_secondary; a.tmax_s = p.tmax_secondary;
-    a.out_rgba8 = ctx->ext_tiles ? ctx->ext_tiles : ctx->d_rgba8;
+    a.out_rgba8 = ext_tiles ? ext_tiles : ctx->d_rgba8;
     a.out_f32 = want_f32 ? ctx->d_f32 : nullptr;
     a.counters = ctx->d_cnt->counters;
     a.ray_shards = ctx->d_cnt->shards;
@@ -532,17 +557,19 @@ int rr_dispatch_rays(rr_context* ctx, uint32_t width, uint32_t height, const rr_
     a.diag = nullptr;
     unsigned long long* d_diag = nullptr;
     const char* diag_path = getenv("RR_DEBUG_DIAG");
-    if (diag_path && ctx->single_identity) { RR_HIP(hipMalloc(&d_diag, (size_t)a.n_blocks * 4 * 32)); a.diag = d_diag; }
+    if (diag_path && ctx->single_identity && depth == 1) { RR_HIP(hipMalloc(&d_diag, (size_t)a.n_blocks * 4 * 32)); a.diag = d_diag; }
 
     const bool stats = (p.flags & RR_DISPATCH_COLLECT_STATS) != 0;
     const uint32_t need = scene_stack_need(ctx);
-    const bool keep = ctx->accumulate_counters || (p.flags & RR_DISPATCH_KEEP_COUNTERS) != 0;
+    const bool keep = keep_counters || (p.flags & RR_DISPATCH_KEEP_COUNTERS) != 0;
     if (!keep) RR_HIP(hipMemsetAsync(ctx->d_cnt, 0, sizeof(CounterBlock), ctx->stream));
-    if (a.compact_out && local < max_local)   // keep the gathered tail deterministic
-        RR_HIP(hipMemsetAsync(a.out_rgba8 + (size_t)local * TILE * TILE, 0, (size_t)(max_local - local) * TILE * TILE * 4, ctx->stream));
+    if (compact && local < max_local)            // keep the gathered tail deterministic
+        for (uint32_t f = 0; f < depth; ++f)
+            RR_HIP(hipMemsetAsync(a.out_rgba8 + f * stride + (size_t)local * TILE * TILE, 0,
+                                  (size_t)(max_local - local) * TILE * TILE * 4, ctx->stream));
     const bool timed = (p.flags & RR_DISPATCH_TIME_KERNEL) != 0;
     if (timed) {
-        if (ctx->kev_used >= 4096) return fail(ctx, RR_ERR_STATE, "rr_dispatch_rays: 4096 timed dispatches pending, call rr_kernel_time");
+        if (ctx->kev_used >= 4096) return fail(ctx, RR_ERR_STATE, "dispatch: 4096 timed dispatches pending, call rr_kernel_time");
         while (ctx->kev.size() < (size_t)(ctx->kev_used + 1) * 2) {
             hipEvent_t e;
             RR_HIP(hipEventCreate(&e));
@@ -552,7 +579,12 @@ int rr_dispatch_rays(rr_context* ctx, uint32_t width, uint32_t height, const rr_
     }
     int stack_sel = need <= 16 ? 16 : need <= 24 ? 24 : need <= 32 ? 32 : 64;
     if (const char* ov = getenv("RR_DEBUG_STACK")) stack_sel = atoi(ov);   // experiments only
-    RR_HIP(launch_render_fused(sc, a, stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream));
+    LdsPlan plan;
+    const MeshRes* m0 = ctx->single_identity ? &ctx->meshes[(size_t)ctx->inst_host[0].blas] : nullptr;
+    if (!a.diag && m0 && plan_render_lds(sc, a, m0->n_tris > 1 ? m0->n_tris - 1 : 1, m0->depth, p.max_reflect <= 2 ? 2 : 8, plan))
+        RR_HIP(launch_render_lds(sc, a, plan, stats, ctx->n_cus, ctx->stream));
+    else
+        RR_HIP(launch_render_fused(sc, a, stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream));
     if (timed) {
         RR_HIP(hipEventRecord(ctx->kev[(size_t)ctx->kev_used * 2 + 1], ctx->stream));
         ++ctx->kev_used;
@@ -564,8 +596,8 @@ int rr_dispatch_rays(rr_context* ctx, uint32_t width, uint32_t height, const rr_
         (void)hipFree(d_diag);
         if (FILE* f = fopen(diag_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
-    ctx->W = width; ctx->H = height; ctx->frame_world = ctx->tile_world;
-    ctx->have_f32 = want_f32; ctx->have_frame = ctx->ext_tiles == nullptr; ctx->have_assembled = false;
+    ctx->W = width; ctx->H = height; ctx->frame_world = ctx->tile_world; ctx->frame_depth = depth;
+    ctx->have_f32 = want_f32; ctx->have_frame = ext_tiles == nullptr; ctx->have_assembled = false;
     ctx->last_stats = stats;
     // pixels actually owned by this rank (partial edge tiles counted exactly)
     uint64_t px = 0;
@@ -574,24 +606,57 @@ int rr_dispatch_rays(rr_context* ctx, uint32_t width, uint32_t height, const rr_
         uint32_t w = width - x0 < TILE ? width - x0 : TILE, h = height - y0 < TILE ? height - y0 : TILE;
         px += (uint64_t)w * h;
     }
-    ctx->last_pixels = (uint32_t)px;
+    px *= depth;
+    ctx->last_pixels = px;
     ctx->accum_pixels = (keep ? ctx->accum_pixels : 0) + px;
     return RR_OK;
 }
 
-int rr_read_frame(rr_context* ctx, uint8_t* rgba8, float* rgba32f)
+int upload_cams(rr_context* ctx, const rr_scene_constants* c, size_t n)
+{
+    static_assert(sizeof(CamDev) == sizeof(rr_scene_constants), "constant buffer layout");
+    if (int r = ensure_cams(ctx, n)) return r;
+    RR_HIP(hipMemcpyAsync(ctx->d_cams, c, n * sizeof(CamDev), hipMemcpyHostToDevice, ctx->stream));   // copy_to_buffer, :566
+    return RR_OK;
+}
+
+} // namespace
+
+int rr_dispatch_rays(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispatch_params* params)
+{
+    if (int r = use_device(ctx)) return r;
+    if (!ctx->cam_set) return fail(ctx, RR_ERR_STATE, "rr_dispatch_rays: rr_set_camera first");
+    rr_dispatch_params p;
+    if (params) p = *params; else rr_default_dispatch_params(&p);
+    if (int r = upload_cams(ctx, &ctx->cam, 1)) return r;
+    return dispatch_impl(ctx, width, height, 1, ctx->d_cams, p, nullptr, 0, false);
+}
+
+int rr_dispatch_rays_batch(rr_context* ctx, uint32_t width, uint32_t height, uint32_t depth,
+                           const rr_scene_constants* constants, const rr_dispatch_params* params)
+{
+    if (int r = use_device(ctx)) return r;
+    if (!constants || depth == 0) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_dispatch_rays_batch: need depth >= 1 constants");
+    rr_dispatch_params p;
+    if (params) p = *params; else rr_default_dispatch_params(&p);
+    if (int r = upload_cams(ctx, constants, depth)) return r;
+    return dispatch_impl(ctx, width, height, depth, ctx->d_cams, p, nullptr, 0, false);
+}
+
+int rr_read_frame_slice(rr_context* ctx, uint32_t slice, uint8_t* rgba8, float* rgba32f)
 {
     if (int r = use_device(ctx)) return r;
     if (!ctx->have_frame) return fail(ctx, RR_ERR_STATE, "rr_read_frame: nothing dispatched");
     const size_t n = (size_t)ctx->W * ctx->H;
     if (ctx->have_assembled) {
-        if (rgba32f) return fail(ctx, RR_ERR_STATE, "rr_read_frame: float output is not gathered across ranks");
+        if (rgba32f || slice) return fail(ctx, RR_ERR_STATE, "rr_read_frame: only slice 0 / RGBA8 of an assembled frame");
         if (rgba8) RR_HIP(hipMemcpyAsync(rgba8, ctx->d_assembled, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     } else {
         if (ctx->frame_world != 1) return fail(ctx, RR_ERR_STATE, "rr_read_frame: sharded frame, gather + rr_assemble_tiles first");
+        if (slice >= ctx->frame_depth) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_read_frame: slice beyond the dispatch depth");
         if (rgba32f && !ctx->have_f32) return fail(ctx, RR_ERR_STATE, "rr_read_frame: dispatch with RR_DISPATCH_FLOAT_OUTPUT");
-        if (rgba8) RR_HIP(hipMemcpyAsync(rgba8, ctx->d_rgba8, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (rgba32f) RR_HIP(hipMemcpyAsync(rgba32f, ctx->d_f32, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+        if (rgba8) RR_HIP(hipMemcpyAsync(rgba8, ctx->d_rgba8 + slice * n, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (rgba32f) RR_HIP(hipMemcpyAsync(rgba32f, ctx->d_f32 + slice * n, n * 16, hipMemcpyDeviceToHost, ctx->stream));
     }
     RR_HIP(hipStreamSynchronize(ctx->stream));
     uint32_t err = 0;
@@ -599,6 +664,8 @@ int rr_read_frame(rr_context* ctx, uint8_t* rgba8, float* rgba32f)
     if (err) return fail(ctx, RR_ERR_TRAVERSAL_OVERFLOW, "traversal stack overflow: frame invalid");
     return RR_OK;
 }
+
+int rr_read_frame(rr_context* ctx, uint8_t* rgba8, float* rgba32f) { return rr_read_frame_slice(ctx, 0, rgba8, rgba32f); }
 
 int rr_export_tiles(rr_context* ctx, void* d_dst)
 {
@@ -635,55 +702,59 @@ int rr_assemble_tiles(rr_context* ctx, const void* d_gathered, uint32_t world, v
     return RR_OK;
 }
 
-int rr_render_orbit(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispatch_params* params, float* angle,
-                    float angle_step, uint32_t n_frames, float fov_y, float aspect, float zn, float zf)
+namespace {
+
+// drawFrame loop: camera constants for n_frames consecutive orbit angles go to the device constant
+// buffer in one copy; the frames are then dispatched in batches of `batch` depth slices.
+int orbit_impl(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispatch_params* params, float* angle,
+               float angle_step, uint32_t n_frames, uint32_t batch, float fov_y, float aspect, float zn, float zf,
+               uint32_t* ext_tiles, size_t ext_stride_elems)
 {
-    if (int r = use_device(ctx)) return r;
-    if (!angle) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_render_orbit: null angle");
+    if (!angle) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "render_orbit: null angle");
+    if (n_frames == 0) return RR_OK;
+    if (batch == 0) batch = 1;
     rr_dispatch_params p;
     if (params) p = *params; else rr_default_dispatch_params(&p);
-    int rc = RR_OK;
-    for (uint32_t k = 0; k < n_frames && rc == RR_OK; ++k) {
-        rr_scene_constants sc;
-        rc = rr_host_camera_orbit(*angle, fov_y, aspect, zn, zf, &sc);          // RefractionDemo.cpp:559-565
-        if (rc != RR_OK) { fail(ctx, rc, "rr_render_orbit: camera"); break; }
-        ctx->cam = sc; ctx->cam_set = true;                                     // :566
-        *angle += angle_step;                                                   // :567
-        ctx->accumulate_counters = k > 0;      // counters are zeroed once, before the first frame
-        rc = rr_dispatch_rays(ctx, width, height, &p);                          // :580-594
+    std::vector<rr_scene_constants> cams(n_frames);
+    for (uint32_t k = 0; k < n_frames; ++k) {
+        int rc = rr_host_camera_orbit(*angle, fov_y, aspect, zn, zf, &cams[k]);      // RefractionDemo.cpp:559-565
+        if (rc != RR_OK) return fail(ctx, rc, "render_orbit: camera");
+        *angle += angle_step;                                                       // :567
     }
-    ctx->accumulate_counters = false;
-    return rc;
+    ctx->cam = cams.back(); ctx->cam_set = true;
+    if (int r = upload_cams(ctx, cams.data(), n_frames)) return r;
+    const bool keep_first = (p.flags & RR_DISPATCH_KEEP_COUNTERS) != 0;
+    for (uint32_t k = 0; k < n_frames; k += batch) {
+        const uint32_t d = n_frames - k < batch ? n_frames - k : batch;
+        uint32_t* ext = ext_tiles ? ext_tiles + (size_t)k * ext_stride_elems : nullptr;
+        if (int rc = dispatch_impl(ctx, width, height, d, ctx->d_cams + k, p, ext, ext_stride_elems, k > 0 || keep_first)) return rc;
+    }
+    return RR_OK;
+}
+
+} // namespace
+
+int rr_render_orbit(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispatch_params* params, float* angle,
+                    float angle_step, uint32_t n_frames, uint32_t frames_per_dispatch, float fov_y, float aspect, float zn,
+                    float zf)
+{
+    if (int r = use_device(ctx)) return r;
+    return orbit_impl(ctx, width, height, params, angle, angle_step, n_frames, frames_per_dispatch, fov_y, aspect, zn, zf,
+                      nullptr, 0);
 }
 
 int rr_render_orbit_sharded(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispatch_params* params, float* angle,
-                            float angle_step, uint32_t n_frames, float fov_y, float aspect, float zn, float zf,
-                            void* d_tiles, uint64_t frame_stride_bytes)
+                            float angle_step, uint32_t n_frames, uint32_t frames_per_dispatch, float fov_y, float aspect,
+                            float zn, float zf, void* d_tiles, uint64_t frame_stride_bytes)
 {
     if (int r = use_device(ctx)) return r;
-    if (!angle || !d_tiles) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_render_orbit_sharded: null argument");
+    if (!d_tiles) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_render_orbit_sharded: null tile buffer");
     uint32_t tx, nt, local, mx;
     tile_counts(width ? width : 1, height ? height : 1, ctx->tile_rank, ctx->tile_world, tx, nt, local, mx);
     if (frame_stride_bytes < (uint64_t)mx * TILE * TILE * 4 || (frame_stride_bytes & 3u))
         return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_render_orbit_sharded: frame stride smaller than a tile buffer");
-    rr_dispatch_params p;
-    if (params) p = *params; else rr_default_dispatch_params(&p);
-    if (p.flags & RR_DISPATCH_FLOAT_OUTPUT) return fail(ctx, RR_ERR_UNSUPPORTED, "rr_render_orbit_sharded: RGBA8 tiles only");
-    const bool keep_first = (p.flags & RR_DISPATCH_KEEP_COUNTERS) != 0;
-    int rc = RR_OK;
-    for (uint32_t k = 0; k < n_frames && rc == RR_OK; ++k) {
-        rr_scene_constants sc;
-        rc = rr_host_camera_orbit(*angle, fov_y, aspect, zn, zf, &sc);
-        if (rc != RR_OK) { fail(ctx, rc, "rr_render_orbit_sharded: camera"); break; }
-        ctx->cam = sc; ctx->cam_set = true;
-        *angle += angle_step;
-        ctx->accumulate_counters = k > 0 || keep_first;
-        ctx->ext_tiles = (uint32_t*)((char*)d_tiles + (size_t)k * frame_stride_bytes);
-        rc = rr_dispatch_rays(ctx, width, height, &p);
-    }
-    ctx->ext_tiles = nullptr;
-    ctx->accumulate_counters = false;
-    return rc;
+    return orbit_impl(ctx, width, height, params, angle, angle_step, n_frames, frames_per_dispatch, fov_y, aspect, zn, zf,
+                      (uint32_t*)d_tiles, (size_t)(frame_stride_bytes / 4));
 }
 
 int rr_assemble_frames(rr_context* ctx, const void* d_gathered, uint32_t world, uint64_t rank_stride_bytes,

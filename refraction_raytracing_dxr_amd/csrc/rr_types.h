@@ -62,9 +62,17 @@ struct SceneDev {
     int32_t env_w, env_h;
 };
 
-struct DispatchDev {
+// SceneConstants as they sit in the device-side constant buffer (RefractionDemo.cpp:533-534, :566)
+struct CamDev {
     float M[16];              // proj_inv, CPU row-major bytes
     float cam[4];
+};
+
+struct DispatchDev {
+    const CamDev* cams;       // one per depth slice of the dispatch (DispatchRays(W,H,Depth))
+    uint32_t n_frames;        // Depth
+    uint32_t blocks_per_frame;
+    size_t   frame_stride;    // output elements between consecutive slices
     uint32_t W, H;
     uint32_t tiles_x, n_tiles;      // 32x32 tiles over the frame
     uint32_t tile_rank, tile_world;
@@ -80,6 +88,14 @@ struct DispatchDev {
     uint32_t* ray_shards;           // RAY_SHARDS u32 partial ray counts
     uint32_t* error_flag;
     unsigned long long* diag;       // diagnostic builds only: 4 x u64 per wave {start, cycles, rays(max lane), loop trips}
+};
+
+// geometry of the LDS-resident persistent kernel (k_render_lds)
+struct LdsPlan {
+    uint32_t n_nodes;          // BvhNode records copied into LDS by every block
+    uint32_t stack_cap;        // traversal stack entries per lane
+    uint32_t waves;            // waves per block
+    uint32_t n_wave_tiles;     // 8x8-pixel patches this rank renders (16 per local 32x32 tile)
 };
 
 enum Counter : int {

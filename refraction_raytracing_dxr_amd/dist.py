@@ -154,7 +154,7 @@ class ShardedFrames:
             if done > 0:
                 p.flags |= DISPATCH_KEEP_COUNTERS
             angle = self.r.render_orbit_sharded(self.width, self.height, nf, self.send[slot].data_ptr(), self.frame_bytes,
-                                                angle=angle, angle_step=angle_step, params=p)
+                                                angle=angle, angle_step=angle_step, params=p, frames_per_dispatch=nf)
             work = self._gather(slot, nf)
             if pending is not None:
                 self._finish(pending)

@@ -184,11 +184,19 @@ class Renderer:
         self._ck(self._L.rr_dispatch_rays(self._h, width, height, C.byref(p)), "rr_dispatch_rays")
         self.width, self.height = width, height
 
-    def read_frame(self, want_float=False):
+    def dispatch_rays_batch(self, width, height, constants, params=None):
+        """DispatchRays(W, H, Depth=len(constants)): one launch, slice f rendered with constants[f]."""
+        p = params if params is not None else default_params()
+        arr = (SceneConstants * len(constants))(*constants)
+        self._ck(self._L.rr_dispatch_rays_batch(self._h, width, height, len(constants), C.cast(arr, C.c_void_p),
+                                                C.byref(p)), "rr_dispatch_rays_batch")
+        self.width, self.height = width, height
+
+    def read_frame(self, want_float=False, slice=0):
         """-> rgba8 uint8 [h,w,4] (and float32 [h,w,4] if the dispatch kept it)."""
         rgba = np.empty((self.height, self.width, 4), np.uint8)
         f32 = np.empty((self.height, self.width, 4), np.float32) if want_float else None
-        self._ck(self._L.rr_read_frame(self._h, rgba.ctypes.data, f32.ctypes.data if want_float else None),
+        self._ck(self._L.rr_read_frame_slice(self._h, slice, rgba.ctypes.data, f32.ctypes.data if want_float else None),
                  "rr_read_frame")
         return (rgba, f32) if want_float else rgba
 
@@ -204,24 +212,26 @@ class Renderer:
         self._ck(self._L.rr_assemble_tiles(self._h, C.c_void_p(gathered_ptr), world,
                                            C.c_void_p(frame_ptr) if frame_ptr else None), "rr_assemble_tiles")
 
-    def render_orbit(self, width, height, n_frames, angle=0.01, angle_step=0.01, params=None, fov_y=FOV_Y,
-                     aspect=ASPECT, zn=1.0, zf=125.0):
+    def render_orbit(self, width, height, n_frames, angle=0.01, angle_step=0.01, params=None, frames_per_dispatch=1,
+                     fov_y=FOV_Y, aspect=ASPECT, zn=1.0, zf=125.0):
         """n_frames of the drawFrame loop (camera -> DispatchRays -> angle += step), asynchronous.
         Returns the angle the next frame would use."""
         p = params if params is not None else default_params()
         a = C.c_float(float(np.float32(angle)))
         self._ck(self._L.rr_render_orbit(self._h, width, height, C.byref(p), C.byref(a), float(np.float32(angle_step)),
-                                         n_frames, fov_y, aspect, zn, zf), "rr_render_orbit")
+                                         n_frames, frames_per_dispatch, fov_y, aspect, zn, zf), "rr_render_orbit")
         self.width, self.height = width, height
         return a.value
 
     def render_orbit_sharded(self, width, height, n_frames, tiles_ptr, frame_stride_bytes, angle=0.01,
-                             angle_step=0.01, params=None, fov_y=FOV_Y, aspect=ASPECT, zn=1.0, zf=125.0):
+                             angle_step=0.01, params=None, frames_per_dispatch=1, fov_y=FOV_Y, aspect=ASPECT, zn=1.0,
+                             zf=125.0):
         p = params if params is not None else default_params()
         a = C.c_float(float(np.float32(angle)))
         self._ck(self._L.rr_render_orbit_sharded(self._h, width, height, C.byref(p), C.byref(a),
-                                                 float(np.float32(angle_step)), n_frames, fov_y, aspect, zn, zf,
-                                                 C.c_void_p(tiles_ptr), frame_stride_bytes), "rr_render_orbit_sharded")
+                                                 float(np.float32(angle_step)), n_frames, frames_per_dispatch, fov_y,
+                                                 aspect, zn, zf, C.c_void_p(tiles_ptr), frame_stride_bytes),
+                 "rr_render_orbit_sharded")
         self.width, self.height = width, height
         return a.value
 

@@ -412,3 +412,56 @@ def test_refraction_demo_mirror(tmp_path, env_png):
     lit = s.render(M, cam, 1024, 768, O.default_params(use_bvh=1), region=(x0, y0, x0 + 64, y0 + 64))
     assert np.abs(f0[y0:y0 + 64, x0:x0 + 64].astype(int) - lit["rgba8"][y0:y0 + 64, x0:x0 + 64].astype(int)).max() <= 1
     demo.renderer.close()
+
+
+# ------------------------------------------------------------------------------- depth slices
+def test_batched_dispatch_equals_single_dispatches(gpu):
+    """DispatchRays(W,H,Depth): every slice is byte-identical to a Depth=1 dispatch with the same constants,
+    and the ray counter is the sum."""
+    m = load("monkey.obj")
+    env = procedural_env(128, 64, seed=13)
+    gpu_scene(gpu, [m], env)
+    gpu.set_tile_partition(0, 1)
+    W, H = 300, 170
+    cams = [rr.camera_orbit(0.01 * (k + 1) + 0.5 * k) for k in range(5)]
+    p = rr.default_params(max_refract=8, flags=rr.DISPATCH_FLOAT_OUTPUT)
+    singles, rays = [], 0
+    for c in cams:
+        gpu.set_camera(c)
+        gpu.dispatch_rays(W, H, p)
+        singles.append([x.copy() for x in gpu.read_frame(want_float=True)])
+        rays += gpu.stats().rays
+    gpu.dispatch_rays_batch(W, H, cams, p)
+    assert gpu.stats().rays == rays and gpu.stats().pixels == 5 * W * H
+    for k in range(5):
+        rgba, f32 = gpu.read_frame(want_float=True, slice=k)
+        assert np.array_equal(rgba, singles[k][0])
+        assert np.array_equal(f32.view(np.uint32), singles[k][1].view(np.uint32))
+    with pytest.raises(rr.RRError):
+        gpu.read_frame(slice=5)
+
+
+def test_orbit_loop_matches_draw_frame_sequence(gpu):
+    """rr_render_orbit (the drawFrame loop in C) with 1 and with 4 frames per dispatch == explicit frames."""
+    m = load("shell.obj")
+    env = procedural_env(128, 64, seed=17)
+    gpu_scene(gpu, [m], env)
+    W, H = 256, 192
+    p = rr.default_params()
+    ref = []
+    a = np.float32(0.01)
+    for k in range(6):
+        gpu.set_camera(rr.camera_orbit(a))
+        gpu.dispatch_rays(W, H, p)
+        ref.append(gpu.read_frame().copy())
+        a = np.float32(a + np.float32(0.01))
+    nxt = gpu.render_orbit(W, H, 6, params=p, frames_per_dispatch=1)
+    assert abs(nxt - 0.07) < 1e-6
+    assert np.array_equal(gpu.read_frame(), ref[5])
+    gpu.render_orbit(W, H, 6, params=p, frames_per_dispatch=4)          # launches of 4 + 2 slices
+    assert np.array_equal(gpu.read_frame(slice=0), ref[4]) and np.array_equal(gpu.read_frame(slice=1), ref[5])
+    total = gpu.stats().rays
+    gpu.render_orbit(W, H, 6, params=p, frames_per_dispatch=6)
+    assert gpu.stats().rays == total
+    for k in range(6):
+        assert np.array_equal(gpu.read_frame(slice=k), ref[k])

@@ -17,18 +17,18 @@ for _ in range(3):
     r.wait()
 d = np.fromfile("/tmp/diag.bin", dtype=np.uint64).reshape(-1, 4).astype(np.float64)
 d = d[d[:, 1] > 0]
-t0 = d[:, 0].min()
-start, cyc, rays, trips = d[:, 0] - t0, d[:, 1], d[:, 2], d[:, 3]
-end = start + cyc
-print("waves %d  kernel span %.0f ticks (s_memtime @100MHz => %.1f us)" % (len(d), end.max(), end.max() / 100.0))
+raw0 = np.fromfile("/tmp/diag.bin", dtype=np.uint64).reshape(-1, 4)
+raw0 = raw0[raw0[:, 1] > 0][:, 0]
+cyc, rays, trips = d[:, 1], d[:, 2], d[:, 3]
+if os.environ.get("RR_DEBUG_KERNEL") != "sync":
+    tI, tL, tS = (raw0 >> np.uint64(40)).astype(float), ((raw0 >> np.uint64(20)) & np.uint64(0xfffff)).astype(float), (raw0 & np.uint64(0xfffff)).astype(float)
+    w = np.argmax(cyc)
+    print("async phases: total trips I/L/S = %.0f / %.0f / %.0f ; worst wave I/L/S = %.0f / %.0f / %.0f" % (tI.sum(), tL.sum(), tS.sum(), tI[w], tL[w], tS[w]))
+print("waves %d" % len(d))
 print("wave cycles(ticks): mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f" % (cyc.mean(), *np.percentile(cyc, [50, 90, 99]), cyc.max()))
 print("rays/lane max-in-wave: mean %.2f max %d ; trips: mean %.0f p99 %.0f max %.0f" % (rays.mean(), rays.max(), trips.mean(), np.percentile(trips, 99), trips.max()))
 heavy = trips > 200
 print("heavy waves (>200 trips): %d ; their ticks/trip: mean %.2f  (=> %.0f ns per trip)" % (heavy.sum(), (cyc[heavy] / trips[heavy]).mean(), (cyc[heavy] / trips[heavy]).mean() * 10))
-order = np.argsort(end)
-print("last 5 waves to finish: end(us) %s  trips %s rays %s" % (np.round(end[order[-5:]] / 100, 1), trips[order[-5:]], rays[order[-5:]]))
-# concurrency over time
-edges = np.linspace(0, end.max(), 21)
-for a, b in zip(edges[:-1], edges[1:]):
-    active = ((start < b) & (end > a)).sum()
-    print("  t %6.1f-%6.1f us: %5d waves alive" % (a / 100, b / 100, active))
+w = np.argsort(cyc)[-5:]
+print("5 longest waves: cycles %s trips %s rays %s => cycles/trip %s" % (cyc[w], trips[w], rays[w], np.round(cyc[w]/trips[w])))
+print("sum of trips over all waves: %.0f" % trips.sum())
