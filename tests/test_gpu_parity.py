@@ -8,6 +8,8 @@ Bars (stated once, used below):
   * frame, RGBA8: <= 1 LSB per channel against the literal oracle, identical against path-weight.
   * exact counters (rays, hits, misses, terminal hits, TIR) equal the oracle's.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -465,3 +467,63 @@ def test_orbit_loop_matches_draw_frame_sequence(gpu):
     assert gpu.stats().rays == total
     for k in range(6):
         assert np.array_equal(gpu.read_frame(slice=k), ref[k])
+
+
+# ------------------------------------------------------------------------------- N > 1 pipeline
+def _sharded_worker(rank, world, port, backend, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)                       # every rank shares the one card of the test box
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    m = load("monkey.obj")
+    env = procedural_env(128, 64, seed=21)
+    r = rr.Renderer(0)
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
+    r.load_scene(m.verts, m.indices, env)
+    W, H, K, F = 250, 130, 7, 3
+    sf = rr.dist.ShardedFrames(r, W, H, rank, world, torch.device("cuda", 0), frames_per_gather=F)
+    rays = sf.render_orbit(K, angle=0.01, params=rr.default_params(max_refract=8))
+    tot = torch.tensor([rays], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(tot)
+    if rank == 0:
+        got = sf.frames_host()                     # the last batch: frames 6.. (K=7, F=3 -> batches 3,3,1)
+        r.set_tile_partition(0, 1)
+        a = np.float32(0.01)
+        ref_rays = 0
+        frames = []
+        for k in range(K):
+            r.set_camera(rr.camera_orbit(a))
+            r.dispatch_rays(W, H, rr.default_params(max_refract=8))
+            frames.append(r.read_frame().copy())
+            ref_rays += r.stats().rays
+            a = np.float32(a + np.float32(0.01))
+        ok = len(got) == 1 and np.array_equal(got[0], frames[6]) and int(tot.item()) == ref_rays
+        np.save(out, np.array([int(ok), len(got), int(tot.item()), ref_rays]))
+    if world > 1:
+        dist.barrier()
+    r.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo")])
+def test_sharded_frames_pipeline(tmp_path, world, backend):
+    """render -> (RCCL | gloo-staged) gather of F frames -> rr_assemble_frames, pipelined over batches,
+    equals frame-by-frame single-GPU rendering.  world 2 runs two processes on the one card."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = str(tmp_path / "ok.npy")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, backend, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    ok = np.load(out)
+    assert ok[0] == 1, ok

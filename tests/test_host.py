@@ -1,0 +1,229 @@
+"""Host side of the product (no GPU): OBJ loader, camera math, image decode, C-ABI surface."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle as O
+import refraction_raytracing_dxr_amd as rr
+from refraction_raytracing_dxr_amd import _capi
+from test_oracle_goldens import CAMERA_KATS, LOADER_GOLD, M_GOLD
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------------------------- C ABI surface
+def declared_functions():
+    """every function prototype in include/rrdxr.h"""
+    src = open(os.path.join(ROOT, "include", "rrdxr.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rr_[a-z0-9_]+)\s*\(", src)) - {"rr_context"})
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(rr.lib_path())
+    names = declared_functions()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), "librrdxr.so lacks %s declared in include/rrdxr.h" % n
+    # and the binding table covers the header exactly
+    assert sorted(_capi.SYMBOLS) == names
+    assert rr.lib().rr_abi_version() == 1
+
+
+def test_header_compiles_as_c_and_structs_have_the_documented_sizes(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "rrdxr.h"\n'
+                   '_Static_assert(sizeof(rr_vertex) == 32, "vertex");\n'
+                   '_Static_assert(sizeof(rr_instance_desc) == 64, "instance");\n'
+                   '_Static_assert(sizeof(rr_scene_constants) == 80, "constants");\n'
+                   '_Static_assert(sizeof(rr_ray) == 48 && sizeof(rr_hit) == 24, "ray/hit");\n'
+                   'int main(void) { return 0; }\n')
+    import subprocess
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o",
+                    str(tmp_path / "t.o")], check=True)
+
+
+def test_no_device_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(rr.RRError) as e:
+        rr.Renderer(0)
+    assert e.value.status == 2          # RR_ERR_NO_DEVICE
+    h = C.c_void_p()
+    assert rr.lib().rr_create(0, C.byref(h)) == 2 and not h.value
+
+
+def test_default_params_are_the_shader_literals():
+    p = rr.default_params()
+    assert (p.max_refract, p.max_reflect) == (5, 2)                       # RayTracing.hlsl:82,110
+    assert p.ior == np.float32(1.3)                                       # :95
+    assert (p.tmin_primary, p.tmax_primary) == (np.float32(1e-4), 100.0)  # :52-53
+    assert (p.tmin_secondary, p.tmax_secondary) == (np.float32(1e-3), 1000.0)   # :99-100
+    assert p.flags == 0
+
+
+# ---------------------------------------------------------------------------------- Mesh::load
+@pytest.mark.parametrize("name", sorted(LOADER_GOLD))
+def test_mesh_load_matches_reference_hashes(name):
+    tris, h, lo, hi = LOADER_GOLD[name]
+    m = rr.Mesh()
+    assert m.load(O.asset(name)) is True
+    assert len(m.verts) == 3 * tris and np.array_equal(m.indices, np.arange(3 * tris, dtype=np.uint32))
+    assert "%016x" % O.fnv1a64(m.verts) == h
+    ov, oi = O.mesh_load(O.asset(name))
+    assert m.verts.tobytes() == ov.tobytes() and np.array_equal(m.indices, oi)
+
+
+def test_mesh_load_edge_cases(tmp_path):
+    m = rr.Mesh()
+    assert m.load(str(tmp_path / "missing.obj")) is False                 # Mesh.cpp:9-10
+    p = tmp_path / "e.obj"
+    p.write_text("")                                                      # empty file: loads, no triangles
+    assert m.load(str(p)) is True and len(m.verts) == 0
+    # sscanf semantics: leading blanks disqualify a line, comments and unknown records are ignored,
+    # a 4th corner is dropped, 'v' wins over 'vt'/'vn' only if three floats follow
+    p.write_text("# c\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\n v 9 9 9\nvt 0 0\nvt 1 1\nvn 0 0 1\n"
+                 "l 1 2\nf 1/1/1 2/2/1 3/1/1 4/2/1\nf 1//1 2//1 3//1\nf 4/2/1 3/1/1 2/2/1\n")
+    m = rr.Mesh()
+    assert m.load(str(p)) and len(m.verts) == 6
+    assert np.array_equal(m.verts["position"][3], (0, 0, 1)) and np.array_equal(m.verts["uv"][1], (1, 1))
+    ov, _ = O.mesh_load(str(p))
+    assert m.verts.tobytes() == ov.tobytes()
+    # loading twice appends, indices keep counting (Mesh.cpp:31-32)
+    assert m.load(str(p)) and len(m.verts) == 12 and m.indices[-1] == 11
+    # out-of-range references: the reference reads wild memory; this loader refuses
+    p.write_text("v 0 0 0\nvt 0 0\nvn 0 0 1\nf 1/1/1 2/1/1 1/1/1\n")
+    assert rr.Mesh().load(str(p)) is False
+
+
+# ---------------------------------------------------------------------------------- camera
+def test_camera_matches_oracle_and_kats():
+    for a in (0.01, 0.02, 1.0, 3.14, 6.28, -0.5):
+        sc = rr.camera_orbit(a)
+        M, cam = O.camera(a)
+        assert np.allclose(np.array(sc.proj_inv), M, rtol=0, atol=2e-6)
+        assert np.allclose(np.array(sc.camera_loc), cam, rtol=0, atol=1e-6)
+    sc = rr.camera_orbit(0.01)
+    assert np.allclose(np.array(sc.proj_inv).reshape(4, 4), M_GOLD, atol=2e-6)
+    for W, H, x, y, d in CAMERA_KATS:
+        _, dd = O.camera_ray(np.array(sc.proj_inv), np.array(sc.camera_loc), x, y, W, H)
+        assert np.allclose(dd, d, atol=1e-5)
+    bad = _capi.SceneConstants()
+    assert rr.lib().rr_host_camera_orbit(0.01, 0.0, 1.333, 1.0, 125.0, C.byref(bad)) == 1
+
+
+# ---------------------------------------------------------------------------------- stbi_loadf stand-in
+def ref_stb():
+    path = os.path.join(ROOT, "oracle", "_ref", "libstb_ref.so")
+    if not os.path.exists(path):
+        return None
+    L = C.CDLL(path)
+    L.stbi_loadf.restype = C.POINTER(C.c_float)
+    L.stbi_loadf.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+    L.stbi_image_free.argtypes = [C.c_void_p]
+    return L
+
+
+def ref_loadf(path, req):
+    L = ref_stb()
+    x, y, n = C.c_int(), C.c_int(), C.c_int()
+    p = L.stbi_loadf(str(path).encode(), C.byref(x), C.byref(y), C.byref(n), req)
+    if not p:
+        return None, 0
+    oc = req if req else n.value
+    a = np.ctypeslib.as_array(p, shape=(y.value, x.value, oc)).copy()
+    L.stbi_image_free(p)
+    return a, n.value
+
+
+def test_envmap_png_golden():
+    env, n = rr.load_texture(O.asset("envmap.png"), 3)
+    assert env.shape == (480, 640, 3) and n == 4
+    assert "%016x" % O.fnv1a64(env) == "38c5be075155201f"
+    assert abs(env.mean() - 0.528603) < 1e-6 and env.max() == 1.0
+    assert abs(env[0, 0, 0] - 0.344026) < 1e-6 and abs(env[240, 320, 0] - 0.529523) < 1e-6
+
+
+def _write_png(path, arr, mode):
+    from PIL import Image
+    Image.fromarray(arr, mode).save(path)
+
+
+@pytest.mark.skipif(ref_stb() is None, reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("req", [0, 1, 2, 3, 4])
+def test_png_decode_bit_exact_vs_reference_stb(tmp_path, req):
+    rng = np.random.default_rng(req)
+    cases = {
+        "rgb.png": (rng.integers(0, 256, (37, 53, 3), dtype=np.uint8), "RGB"),
+        "rgba.png": (rng.integers(0, 256, (19, 64, 4), dtype=np.uint8), "RGBA"),
+        "gray.png": (rng.integers(0, 256, (40, 31), dtype=np.uint8), "L"),
+        "la.png": (rng.integers(0, 256, (16, 16, 2), dtype=np.uint8), "LA"),
+        "smooth.png": (np.tile(np.arange(256, dtype=np.uint8), (64, 1)), "L"),     # exercises the PNG filters
+    }
+    for name, (arr, mode) in cases.items():
+        p = tmp_path / name
+        _write_png(p, arr, mode)
+        mine, n1 = rr.load_texture(p, req)
+        ref, n2 = ref_loadf(p, req)
+        assert n1 == n2 and mine.shape == ref.shape, name
+        assert np.array_equal(mine.view(np.uint32), ref.view(np.uint32)), name
+    # palette and 16-bit
+    from PIL import Image
+    Image.fromarray(cases["rgb.png"][0], "RGB").quantize(17).save(tmp_path / "pal.png")
+    Image.fromarray(rng.integers(0, 65536, (9, 11), dtype=np.uint16)).save(tmp_path / "g16.png")
+    for name in ("pal.png", "g16.png"):
+        mine, n1 = rr.load_texture(tmp_path / name, req)
+        ref, n2 = ref_loadf(tmp_path / name, req)
+        assert n1 == n2 and np.array_equal(mine.view(np.uint32), ref.view(np.uint32)), name
+    mine, _ = rr.load_texture(O.asset("envmap.png"), req)
+    ref, _ = ref_loadf(O.asset("envmap.png"), req)
+    assert np.array_equal(mine.view(np.uint32), ref.view(np.uint32))
+
+
+def test_hdr_write_read_roundtrip(tmp_path):
+    from conftest import procedural_env
+    env = procedural_env(96, 48, seed=2)
+    env[0, :9] = 0.0                                   # a run of black pixels (RLE runs, zero exponent)
+    env[1, 0] = (1e-40, 0, 0)                          # underflows to the all-zero RGBE pixel
+    p = tmp_path / "e.hdr"
+    rr.write_hdr(p, env)
+    back, n = rr.load_texture(p, 3)
+    assert back.shape == env.shape and n == 3
+    mx = env.max(axis=2, keepdims=True)
+    assert np.all(np.abs(back - env) <= mx / 128.0 + 1e-30)     # 8-bit mantissa shared exponent
+    assert np.all(back[0, :9] == 0) and np.all(back[1, 0] == 0)
+    # narrow images are stored flat (width < 8): same pixel values
+    rr.write_hdr(tmp_path / "n.hdr", env[:, :5].copy())
+    nb, _ = rr.load_texture(tmp_path / "n.hdr", 3)
+    assert np.array_equal(nb, back[:, :5])
+    # idempotent once quantised
+    rr.write_hdr(tmp_path / "e2.hdr", back)
+    again, _ = rr.load_texture(tmp_path / "e2.hdr", 3)
+    assert np.array_equal(again, back)
+
+
+@pytest.mark.skipif(ref_stb() is None, reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("req", [0, 1, 3, 4])
+def test_hdr_decode_bit_exact_vs_reference_stb(tmp_path, req):
+    from conftest import procedural_env
+    for w, h in ((96, 48), (5, 7), (8, 3)):
+        p = tmp_path / ("e%dx%d.hdr" % (w, h))
+        rr.write_hdr(p, procedural_env(w, h, seed=w))
+        mine, n1 = rr.load_texture(p, req)
+        ref, n2 = ref_loadf(p, req)
+        assert n1 == n2 == 3 and np.array_equal(mine.view(np.uint32), ref.view(np.uint32))
+
+
+def test_image_load_failures(tmp_path):
+    with pytest.raises(rr.RRError):
+        rr.load_texture(tmp_path / "nope.hdr")
+    (tmp_path / "junk.png").write_bytes(b"\x89PNG\r\n\x1a\n" + b"\0" * 40)
+    with pytest.raises(rr.RRError):
+        rr.load_texture(tmp_path / "junk.png")
+    (tmp_path / "bad.hdr").write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_xyze\n\n-Y 2 +X 2\n" + b"\0" * 16)
+    with pytest.raises(rr.RRError):
+        rr.load_texture(tmp_path / "bad.hdr")
