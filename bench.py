@@ -86,7 +86,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--depth1", action="store_true", help="also time the reference's shape, one DispatchRays per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames-per-dispatch", type=int, default=16,
                     help="depth slices per launch (DispatchRays(W,H,Depth)); N>1: also frames per RCCL gather")
@@ -171,22 +172,25 @@ def main():
         kms, kn = r.kernel_time()                                           # HIP events around each launch, on the launch stream
         bytes_per_launch = algorithmic_bytes(sst) / kn                      # one launch = F frames
         kernel_us = kms / kn * 1e3
-        # the reference's own shape, one DispatchRays per frame (Depth 1), for comparison
-        r.render_orbit(W, H, 32, angle=0.01, frames_per_dispatch=1, params=rr.default_params(
-            max_refract=MAX_REFRACT, max_reflect=MAX_REFLECT, flags=rr.DISPATCH_TIME_KERNEL))
-        k1ms, k1n = r.kernel_time()
+        k1ms, k1n = None, 0
+        if args.depth1:   # the reference's own shape, one DispatchRays per frame (Depth 1), for comparison
+            r.render_orbit(W, H, 32, angle=0.01, frames_per_dispatch=1, params=rr.default_params(
+                max_refract=MAX_REFRACT, max_reflect=MAX_REFLECT, flags=rr.DISPATCH_TIME_KERNEL))
+            k1ms, k1n = r.kernel_time()
         achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                if tj.get("frames_per_launch") == F:
+                    traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "kernel": "k_render_fused", "kernel_us": round(kernel_us, 2), "frames_per_launch": F,
-                    "depth1_kernel_us": round(k1ms / k1n * 1e3, 2),
+                    "depth1_kernel_us": round(k1ms / k1n * 1e3, 2) if k1n else None,
                     "algorithmic_bytes_per_launch": int(bytes_per_launch),
                     "bytes_per_ray": round(algorithmic_bytes(sst) / sst.rays, 1),
                     "survey_formula_bytes_per_ray": round(survey_formula_bytes(sst) / sst.rays, 1),

@@ -120,9 +120,12 @@ typedef struct rr_context rr_context;
 int  rr_create(int device_ordinal, rr_context** out);
 int  rr_destroy(rr_context* ctx);
 const char* rr_last_error(const rr_context* ctx);
-/* Use a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own;
- * NULL restores the context's stream.  Stands where the command queue of :161-166 stood. */
+/* Use a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own, so that
+ * the caller's work on that stream (RCCL collectives, copies) is ordered with the render kernels.
+ * NULL means HIP's default stream.  rr_reset_stream returns to the context's own stream.
+ * Stands where the command queue of :161-166 stood. */
 int  rr_set_stream(rr_context* ctx, void* hip_stream);
+int  rr_reset_stream(rr_context* ctx);
 /* wait_until_finished, RefractionDemo.cpp:65-71 */
 int  rr_wait(rr_context* ctx);
 

@@ -60,6 +60,7 @@ SYMBOLS = {
     "rr_destroy": (C.c_int, [_P]),
     "rr_last_error": (C.c_char_p, [_P]),
     "rr_set_stream": (C.c_int, [_P, _P]),
+    "rr_reset_stream": (C.c_int, [_P]),
     "rr_wait": (C.c_int, [_P]),
     "rr_upload_mesh": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
     "rr_upload_envmap": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),

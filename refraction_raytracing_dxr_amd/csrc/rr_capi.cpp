@@ -287,7 +287,15 @@ int rr_set_stream(rr_context* ctx, void* hip_stream)
 {
     if (int r = use_device(ctx)) return r;
     RR_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream;         // NULL is a stream too: HIP's default stream
+    return RR_OK;
+}
+
+int rr_reset_stream(rr_context* ctx)
+{
+    if (int r = use_device(ctx)) return r;
+    RR_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->stream = ctx->own_stream;
     return RR_OK;
 }
 

@@ -146,7 +146,11 @@ class Renderer:
             raise RRError(rc, "%s: %s" % (what, self._L.rr_last_error(self._h).decode()))
 
     def set_stream(self, hip_stream):
-        self._ck(self._L.rr_set_stream(self._h, C.c_void_p(hip_stream)), "rr_set_stream")
+        """run on a caller-owned hipStream_t handle (0 / None = HIP's default stream)"""
+        self._ck(self._L.rr_set_stream(self._h, C.c_void_p(hip_stream or None)), "rr_set_stream")
+
+    def reset_stream(self):
+        self._ck(self._L.rr_reset_stream(self._h), "rr_reset_stream")
 
     def wait(self):
         self._ck(self._L.rr_wait(self._h), "rr_wait")
