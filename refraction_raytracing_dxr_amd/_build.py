@@ -19,7 +19,7 @@ HEADERS = ["rr_types.h", "rr_device.h", "rr_launch.h", "host/Mesh.hpp", "host/Re
 
 # -ffp-contract=off: the arithmetic contract -- FMAs only where fmaf is written
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
-DEVICE_FLAGS = ["--offload-arch=gfx950", "-fgpu-rdc" if False else "-fno-gpu-rdc"]
+DEVICE_FLAGS = ["--offload-arch=gfx950", "-fno-gpu-rdc"] + os.environ.get("RR_EXTRA_DEFINES", "").split()
 
 
 def _hipcc():

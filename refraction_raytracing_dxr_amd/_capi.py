@@ -26,8 +26,9 @@ INSTANCE_DTYPE = np.dtype([("transform", "<f4", 12), ("instance_id_mask", "<u4")
 RAY_DTYPE = np.dtype([("origin", "<f4", 3), ("tmin", "<f4"), ("dir", "<f4", 3), ("tmax", "<f4"),
                       ("flags", "<u4"), ("pad", "<u4", 3)])
 HIT_DTYPE = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("prim", "<u4"), ("inst", "<u4"), ("hit", "<u4")])
-NODE_DTYPE = np.dtype([("lo0", "<f4", 3), ("hi0", "<f4", 3), ("lo1", "<f4", 3), ("hi1", "<f4", 3),
-                       ("c0", "<i4"), ("c1", "<i4"), ("pad", "<u4", 2)])
+# 64-byte BVH2 node: per plane the pair (child 0, child 1); c = child refs (>= 0 node, < 0 leaf ~ref)
+NODE_DTYPE = np.dtype([("lox", "<f4", 2), ("loy", "<f4", 2), ("loz", "<f4", 2), ("hix", "<f4", 2),
+                       ("hiy", "<f4", 2), ("hiz", "<f4", 2), ("c", "<i4", 2), ("pad", "<u4", 2)])
 TRI_DTYPE = np.dtype([("v0", "<f4", 3), ("prim", "<u4"), ("e1", "<f4", 3), ("pad1", "<u4"),
                       ("e2", "<f4", 3), ("pad2", "<u4")])
 assert VERTEX_DTYPE.itemsize == 32 and INSTANCE_DTYPE.itemsize == 64 and RAY_DTYPE.itemsize == 48

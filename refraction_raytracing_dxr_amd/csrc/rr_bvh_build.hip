@@ -279,11 +279,10 @@ __global__ __launch_bounds__(256) void k_pack_nodes(BuildBuffers b)
     if (n == 1) {
         if (i == 0) {                                   // single primitive: node 0 = {leaf 0, empty}
             BvhNode nd;
-            for (int k = 0; k < 3; ++k) {
-                nd.lo0[k] = b.node_box[k]; nd.hi0[k] = b.node_box[3 + k];
-                nd.lo1[k] = inf; nd.hi1[k] = -inf;
-            }
-            nd.c0 = ~0; nd.c1 = ~0; nd.pad0 = 0; nd.pad1 = 0;
+            nd.lox[0] = b.node_box[0]; nd.loy[0] = b.node_box[1]; nd.loz[0] = b.node_box[2];
+            nd.hix[0] = b.node_box[3]; nd.hiy[0] = b.node_box[4]; nd.hiz[0] = b.node_box[5];
+            nd.lox[1] = nd.loy[1] = nd.loz[1] = inf; nd.hix[1] = nd.hiy[1] = nd.hiz[1] = -inf;
+            nd.c[0] = ~0; nd.c[1] = ~0; nd.pad[0] = 0; nd.pad[1] = 0;
             b.nodes[0] = nd;
         }
         return;
@@ -296,11 +295,11 @@ __global__ __launch_bounds__(256) void k_pack_nodes(BuildBuffers b)
         if (r < 0) r = ~(int)(b.keys[~r] & 0xffffffffull);
     }
     BvhNode nd;
-    for (int k = 0; k < 3; ++k) {
-        nd.lo0[k] = b.node_box[il * 6 + k]; nd.hi0[k] = b.node_box[il * 6 + 3 + k];
-        nd.lo1[k] = b.node_box[ir * 6 + k]; nd.hi1[k] = b.node_box[ir * 6 + 3 + k];
-    }
-    nd.c0 = l; nd.c1 = r; nd.pad0 = 0; nd.pad1 = 0;
+    const float* bl = b.node_box + il * 6;
+    const float* br = b.node_box + ir * 6;
+    nd.lox[0] = bl[0]; nd.loy[0] = bl[1]; nd.loz[0] = bl[2]; nd.hix[0] = bl[3]; nd.hiy[0] = bl[4]; nd.hiz[0] = bl[5];
+    nd.lox[1] = br[0]; nd.loy[1] = br[1]; nd.loz[1] = br[2]; nd.hix[1] = br[3]; nd.hiy[1] = br[4]; nd.hiz[1] = br[5];
+    nd.c[0] = l; nd.c[1] = r; nd.pad[0] = 0; nd.pad[1] = 0;
     b.nodes[i] = nd;
 }
 

@@ -50,8 +50,9 @@ struct SahBuilder {
         const int c0 = build(a, best_split, b0, d + 1);
         const int c1 = build(best_split, b, b1, d + 1);
         BvhNode& n = nodes[id];
-        for (int k = 0; k < 3; ++k) { n.lo0[k] = b0.lo[k]; n.hi0[k] = b0.hi[k]; n.lo1[k] = b1.lo[k]; n.hi1[k] = b1.hi[k]; }
-        n.c0 = c0; n.c1 = c1; n.pad0 = n.pad1 = 0;
+        n.lox[0] = b0.lo[0]; n.loy[0] = b0.lo[1]; n.loz[0] = b0.lo[2]; n.hix[0] = b0.hi[0]; n.hiy[0] = b0.hi[1]; n.hiz[0] = b0.hi[2];
+        n.lox[1] = b1.lo[0]; n.loy[1] = b1.lo[1]; n.loz[1] = b1.lo[2]; n.hix[1] = b1.hi[0]; n.hiy[1] = b1.hi[1]; n.hiz[1] = b1.hi[2];
+        n.c[0] = c0; n.c[1] = c1; n.pad[0] = n.pad[1] = 0;
         out = b0; grow(out, b1);
         return id;
     }

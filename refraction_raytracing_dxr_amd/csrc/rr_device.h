@@ -138,16 +138,49 @@ __device__ __forceinline__ BoxRay box_ray(f3 O, f3 D)
     box_axis(O.z, D.z, r.inv.z, r.klo.z, r.khi.z);
     return r;
 }
-// slab test of one box; returns entry distance in tn
-__device__ __forceinline__ bool box_hit(const BoxRay& r, float lx, float ly, float lz, float hx, float hy, float hz,
-                                        float tmin, float tmax, float& tn)
+constexpr int TRAV_DONE = (int)0x80000000;     // neither an internal index (>= 0) nor a leaf (~i with i < 2^31-1)
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f splat2(float x) { v2f r = { x, x }; return r; }
+__device__ __forceinline__ v2f mk2(float x, float y) { v2f r = { x, y }; return r; }
+
+// slab test of BOTH children of a node (q0,q1,q2 = the node's first three 16-byte words);
+// six v_pk_fma_f32 give the twelve plane distances, tn0/tn1 are the entry distances
+__device__ __forceinline__ void box2_hit(const BoxRay& r, const float4 q0, const float4 q1, const float4 q2, float tmin, float tmax,
+                                         bool& h0, bool& h1, float& tn0, float& tn1)
 {
-    const float ax = fmaf(lx, r.inv.x, r.klo.x), bx = fmaf(hx, r.inv.x, r.khi.x);
-    const float ay = fmaf(ly, r.inv.y, r.klo.y), by = fmaf(hy, r.inv.y, r.khi.y);
-    const float az = fmaf(lz, r.inv.z, r.klo.z), bz = fmaf(hz, r.inv.z, r.khi.z);
-    tn = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), tmin);
-    const float tf = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)), tmax);
-    return tn <= tf * 1.000001f;
+    const v2f ax = __builtin_elementwise_fma(mk2(q0.x, q0.y), splat2(r.inv.x), splat2(r.klo.x));
+    const v2f ay = __builtin_elementwise_fma(mk2(q0.z, q0.w), splat2(r.inv.y), splat2(r.klo.y));
+    const v2f az = __builtin_elementwise_fma(mk2(q1.x, q1.y), splat2(r.inv.z), splat2(r.klo.z));
+    const v2f bx = __builtin_elementwise_fma(mk2(q1.z, q1.w), splat2(r.inv.x), splat2(r.khi.x));
+    const v2f by = __builtin_elementwise_fma(mk2(q2.x, q2.y), splat2(r.inv.y), splat2(r.khi.y));
+    const v2f bz = __builtin_elementwise_fma(mk2(q2.z, q2.w), splat2(r.inv.z), splat2(r.khi.z));
+    tn0 = fmaxf(fmaxf(fmaxf(fminf(ax.x, bx.x), fminf(ay.x, by.x)), fminf(az.x, bz.x)), tmin);
+    tn1 = fmaxf(fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fminf(az.y, bz.y)), tmin);
+    const float tf0 = fminf(fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x)), tmax);
+    const float tf1 = fminf(fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fmaxf(az.y, bz.y)), tmax);
+    h0 = tn0 <= tf0 * 1.000001f;
+    h1 = tn1 <= tf1 * 1.000001f;
+}
+
+// one traversal step at an internal node: returns the next node (near child, or a popped entry, or
+// TRAV_DONE) and pushes the far child when both are hit.  stk: this lane's LDS column, sp0: stack floor.
+template <bool CHECK>
+__device__ __forceinline__ int node_step(const BoxRay& br, const float4 q0, const float4 q1, const float4 q2, const float4 q3,
+                                         float tmin, float tmax, uint32_t* stk, int& sp, int sp0, int cap, uint32_t& err)
+{
+    bool h0, h1;
+    float tn0, tn1;
+    box2_hit(br, q0, q1, q2, tmin, tmax, h0, h1, tn0, tn1);
+    const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+    const bool both = h0 && h1, swap = tn1 < tn0;
+    const int nearc = (h0 && !(h1 && swap)) ? c0 : c1;
+    int next = (h0 || h1) ? nearc : TRAV_DONE;
+    if (both) {
+        if (!CHECK || sp < cap) { stk[sp * 64] = (uint32_t)(swap ? c0 : c1); ++sp; } else err = 1u;
+    }
+    if (!(h0 || h1) && sp > sp0) { --sp; next = (int)stk[sp * 64]; }
+    return next;
 }
 
 // diagnostic builds count wave-level loop trips in LDS (one word per wave); null in product builds
@@ -157,7 +190,6 @@ __device__ __forceinline__ void diag_trip(const Diag& d)
     if (d.trips) { const unsigned long long m = __ballot(1); if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) *d.trips += 1u; }
 }
 
-constexpr int TRAV_DONE = (int)0x80000000;     // neither an internal index (>= 0) nor a leaf (~i with i < 2^31-1)
 
 // scaled Moller-Trumbore; front-facing <=> det > 0.  Equal-t ties go to the lower
 // (instance, primitive) so that the result does not depend on traversal order.
@@ -209,24 +241,7 @@ __device__ __forceinline__ void trace_blas(const BlasDev& bl, f3 O, f3 D, float 
             const float4* q = nodes + (uint32_t)node * 4u;
             const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             if (STATS) cnt.nodes++;
-            // child 0: lo (q0.x,q0.y,q0.z) hi (q0.w,q1.x,q1.y); child 1: lo (q1.z,q1.w,q2.x) hi (q2.y,q2.z,q2.w)
-            float tn0, tn1;
-            const bool h0 = box_hit(br, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmin, best.t, tn0);
-            const bool h1 = box_hit(br, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmin, best.t, tn1);
-            const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-            if (h0 && h1) {
-                const bool swap = tn1 < tn0;
-                const int farc = swap ? c0 : c1;
-                node = swap ? c1 : c0;
-                if (sp < STACK) { stk[sp * 64] = (uint32_t)farc; ++sp; } else *err = 1u;
-            } else if (h0 || h1) {
-                node = h0 ? c0 : c1;
-            } else if (sp > sp0) {
-                --sp;
-                node = (int)stk[sp * 64];
-            } else {
-                node = TRAV_DONE;
-            }
+            node = node_step<true>(br, q0, q1, q2, q3, tmin, best.t, stk, sp, sp0, STACK, *err);
         }
         if (node == TRAV_DONE) break;
         diag_trip(dg);
@@ -272,26 +287,11 @@ __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, floa
             const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             if (STATS) cnt.nodes++;
             // instance boxes are boxes of transformed corners (rounded): grow them by a few ulps
-            float tn0, tn1;
             const float g = 1e-5f;
-            const bool h0 = box_hit(br, q0.x - g * fabsf(q0.x), q0.y - g * fabsf(q0.y), q0.z - g * fabsf(q0.z),
-                                    q0.w + g * fabsf(q0.w), q1.x + g * fabsf(q1.x), q1.y + g * fabsf(q1.y), tmin, best.t, tn0);
-            const bool h1 = box_hit(br, q1.z - g * fabsf(q1.z), q1.w - g * fabsf(q1.w), q2.x - g * fabsf(q2.x),
-                                    q2.y + g * fabsf(q2.y), q2.z + g * fabsf(q2.z), q2.w + g * fabsf(q2.w), tmin, best.t, tn1);
-            const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-            if (h0 && h1) {
-                const bool swap = tn1 < tn0;
-                const int farc = swap ? c0 : c1;
-                node = swap ? c1 : c0;
-                if (sp < STACK) { stk[sp * 64] = (uint32_t)farc; ++sp; } else *err = 1u;
-            } else if (h0 || h1) {
-                node = h0 ? c0 : c1;
-            } else if (sp > 0) {
-                --sp;
-                node = (int)stk[sp * 64];
-            } else {
-                node = TRAV_DONE;
-            }
+            const float4 g0 = make_float4(q0.x - g * fabsf(q0.x), q0.y - g * fabsf(q0.y), q0.z - g * fabsf(q0.z), q0.w - g * fabsf(q0.w));
+            const float4 g1 = make_float4(q1.x - g * fabsf(q1.x), q1.y - g * fabsf(q1.y), q1.z + g * fabsf(q1.z), q1.w + g * fabsf(q1.w));
+            const float4 g2 = make_float4(q2.x + g * fabsf(q2.x), q2.y + g * fabsf(q2.y), q2.z + g * fabsf(q2.z), q2.w + g * fabsf(q2.w));
+            node = node_step<true>(br, g0, g1, g2, q3, tmin, best.t, stk, sp, 0, STACK, *err);
         }
         if (node == TRAV_DONE) break;
         {

@@ -15,6 +15,11 @@
 #include "rr_device.h"
 #include "rr_launch.h"
 
+// minimum waves per SIMD the register allocator must leave room for (96 VGPRs; measured +6..8 % over 4)
+#ifndef RR_FUSED_WAVES_PER_SIMD
+#define RR_FUSED_WAVES_PER_SIMD 5
+#endif
+
 namespace rr {
 
 struct PendRay {
@@ -42,7 +47,7 @@ __device__ __forceinline__ void block_to_tile(uint32_t b, uint32_t& tile_local, 
 }
 
 template <int STACK, int PEND, bool STATS, bool TLAS, bool DIAG = false>
-__global__ __launch_bounds__(256) void k_render_fused(SceneDev sc, DispatchDev a)
+__global__ __launch_bounds__(256, RR_FUSED_WAVES_PER_SIMD) void k_render_fused(SceneDev sc, DispatchDev a)
 {
     __shared__ uint32_t diag_trips[4];
     const unsigned long long diag_t0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -247,23 +252,7 @@ __global__ __launch_bounds__(256) void k_render_async(SceneDev sc, DispatchDev a
                 const float4* q = nodes + (uint32_t)node * 4u;
                 const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
                 if (STATS) ++n_nodes;
-                float tn0, tn1;
-                const bool h0 = box_hit(br, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmin, h.t, tn0);
-                const bool h1 = box_hit(br, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmin, h.t, tn1);
-                const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-                if (h0 && h1) {
-                    const bool swap = tn1 < tn0;
-                    const int farc = swap ? c0 : c1;
-                    node = swap ? c1 : c0;
-                    if (sp < STACK) { stk[sp * 64] = (uint32_t)farc; ++sp; } else err = 1u;
-                } else if (h0 || h1) {
-                    node = h0 ? c0 : c1;
-                } else if (sp > 0) {
-                    --sp;
-                    node = (int)stk[sp * 64];
-                } else {
-                    node = TRAV_DONE;
-                }
+                node = node_step<true>(br, q0, q1, q2, q3, tmin, h.t, stk, sp, 0, STACK, err);
             }
         } else if (nL >= nS) {
             // ---- triangle step ------------------------------------------------------------------------
@@ -435,23 +424,7 @@ __global__ __launch_bounds__(1024) void k_render_lds(SceneDev sc, DispatchDev a,
                     const float4* q = nodes + (uint32_t)node * 4u;
                     const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
                     if (STATS) ++n_nodes;
-                    float tn0, tn1;
-                    const bool h0 = box_hit(br, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmin, h.t, tn0);
-                    const bool h1 = box_hit(br, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmin, h.t, tn1);
-                    const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-                    if (h0 && h1) {
-                        const bool swap = tn1 < tn0;
-                        const int farc = swap ? c0 : c1;
-                        node = swap ? c1 : c0;
-                        if (sp < stack_cap) { stk[sp * 64] = (uint32_t)farc; ++sp; } else err = 1u;
-                    } else if (h0 || h1) {
-                        node = h0 ? c0 : c1;
-                    } else if (sp > 0) {
-                        --sp;
-                        node = (int)stk[sp * 64];
-                    } else {
-                        node = TRAV_DONE;
-                    }
+                    node = node_step<true>(br, q0, q1, q2, q3, tmin, h.t, stk, sp, 0, stack_cap, err);
                 }
             } else if (nL >= nS) {
                 if (wantL) {

@@ -10,12 +10,15 @@
 
 namespace rr {
 
-// child ref: >= 0 internal node index, < 0 leaf holding primitive ~ref (index into TriRec / instances)
+// child ref: >= 0 internal node index, < 0 leaf holding primitive ~ref (index into TriRec / instances).
+// The two child boxes are stored plane-pair by plane-pair, (child0, child1) adjacent, so that one
+// v_pk_fma_f32 evaluates the same slab plane of both children (packed FP32 is the full-rate path on CDNA).
 struct alignas(16) BvhNode {
-    float lo0[3], hi0[3];     // child 0 box
-    float lo1[3], hi1[3];     // child 1 box
-    int32_t c0, c1;
-    uint32_t pad0, pad1;
+    float lox[2], loy[2];     // 16 B: lower x of child 0/1, lower y of child 0/1
+    float loz[2], hix[2];
+    float hiy[2], hiz[2];
+    int32_t c[2];             // child refs
+    uint32_t pad[2];
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 B");
 

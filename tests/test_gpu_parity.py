@@ -186,7 +186,7 @@ def test_lbvh_structure(gpu, name):
     while stack:
         n = stack.pop()
         order.append(n)
-        for c in (nodes["c0"][n], nodes["c1"][n]):
+        for c in nodes["c"][n]:
             if c >= 0:
                 seen_nodes[c] += 1
                 stack.append(c)
@@ -194,8 +194,10 @@ def test_lbvh_structure(gpu, name):
                 seen_leaves[~c] += 1
     assert np.all(seen_nodes == 1) and np.all(seen_leaves == 1)
     for n in reversed(order):
-        for k, (c, l, h) in enumerate(((nodes["c0"][n], nodes["lo0"][n], nodes["hi0"][n]),
-                                       (nodes["c1"][n], nodes["lo1"][n], nodes["hi1"][n]))):
+        for k in (0, 1):
+            c = nodes["c"][n][k]
+            l = np.array([nodes["lox"][n][k], nodes["loy"][n][k], nodes["loz"][n][k]], np.float32)
+            h = np.array([nodes["hix"][n][k], nodes["hiy"][n][k], nodes["hiz"][n][k]], np.float32)
             if c >= 0:
                 elo, ehi = lo[c], hi[c]
             else:

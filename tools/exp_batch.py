@@ -10,7 +10,7 @@ for name in (sys.argv[1:] or ["monkey.obj"]):
     m = rr.Mesh(); m.load(O.asset(name))
     r.load_scene(m.verts, m.indices, procedural_env(2048, 1024, seed=0))
     p = rr.default_params(max_refract=8)
-    for F in (1, 4, 16, 64):
+    for F in (1, 16, 64):
         n = max(64, F * 2)
         r.render_orbit(1920, 1080, F, params=p, frames_per_dispatch=F); r.wait()
         t0 = time.perf_counter()
