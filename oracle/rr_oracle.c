@@ -44,7 +44,7 @@ static inline v3 v3_normalize(v3 a)
  * HLSL atan2/acos are implementation-defined approximations (DXC lowers them
  * to driver intrinsics).  The oracle and the HIP path both use the Cephes
  * single-precision minimax forms below so that texel selection is bit-stable;
- * tests/test_oracle_math.py bounds their distance from libm. */
+ * tests/test_oracle_goldens.py bounds their distance from libm. */
 static float rro_atanf_pos(float x) /* x >= 0 */
 {
     float y0;
@@ -617,11 +617,14 @@ static inline void tri_test(const cpu_mesh* m, uint32_t p, v3 O, v3 D, float tmi
 }
 
 /* conservative slab test; only has to never reject a box whose triangle would be accepted */
-static inline int box_test(const aabb* b, v3 O, v3 inv, float tmin, float tmax)
+/* pad: boxes are grown by 1e-5 of the scene/origin magnitude -- the fp32 triangle test accepts points a
+ * few ulps outside a triangle's edge, and a ray running along the symmetry plane of a mirrored mesh
+ * hits exactly those edges; without the growth the BVH would cull what brute force accepts. */
+static inline int box_test(const aabb* b, v3 O, v3 inv, float tmin, float tmax, float pad)
 {
-    float t0x = (b->lo.x - O.x) * inv.x, t1x = (b->hi.x - O.x) * inv.x;
-    float t0y = (b->lo.y - O.y) * inv.y, t1y = (b->hi.y - O.y) * inv.y;
-    float t0z = (b->lo.z - O.z) * inv.z, t1z = (b->hi.z - O.z) * inv.z;
+    float t0x = (b->lo.x - pad - O.x) * inv.x, t1x = (b->hi.x + pad - O.x) * inv.x;
+    float t0y = (b->lo.y - pad - O.y) * inv.y, t1y = (b->hi.y + pad - O.y) * inv.y;
+    float t0z = (b->lo.z - pad - O.z) * inv.z, t1z = (b->hi.z + pad - O.z) * inv.z;
     float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
     float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
     return tn <= tf * 1.0000004f;
@@ -642,13 +645,17 @@ static void trace_mesh(const cpu_mesh* m, v3 O, v3 D, float tmin, uint32_t flags
     }
     if (!m->n_nodes) return;
     v3 inv = v3_make(safe_rcp(D.x), safe_rcp(D.y), safe_rcp(D.z));
+    const aabb* rb = &m->nodes[0].box;
+    float scale = fmaxf(fmaxf(fmaxf(fabsf(rb->lo.x), fabsf(rb->hi.x)), fmaxf(fabsf(rb->lo.y), fabsf(rb->hi.y))),
+                        fmaxf(fabsf(rb->lo.z), fabsf(rb->hi.z)));
+    float pad = 1e-5f * fmaxf(fmaxf(fabsf(O.x), fabsf(O.y)), fmaxf(fabsf(O.z), scale));
     int32_t stack[128];
     int sp = 0;
     stack[sp++] = 0;
     while (sp) {
         const cpu_node* n = &m->nodes[stack[--sp]];
         if (st) st->node_visits++;
-        if (!box_test(&n->box, O, inv, tmin, best->t)) continue;
+        if (!box_test(&n->box, O, inv, tmin, best->t, pad)) continue;
         if (n->left < 0) {
             for (uint32_t i = 0; i < n->count; ++i)
                 tri_test(m, m->prim_order[n->first + i], O, D, tmin, flags, inst, best, st);
@@ -679,7 +686,11 @@ static void trace_scene(const rro_scene* s, v3 O, v3 D, float tmin, float tmax, 
         } else {
             if (use_bvh) {
                 v3 inv = v3_make(safe_rcp(D.x), safe_rcp(D.y), safe_rcp(D.z));
-                if (!box_test(&ci->world_box, O, inv, tmin, best->t)) continue;
+                const aabb* wb = &ci->world_box;
+                float sc = fmaxf(fmaxf(fmaxf(fabsf(wb->lo.x), fabsf(wb->hi.x)), fmaxf(fabsf(wb->lo.y), fabsf(wb->hi.y))),
+                                 fmaxf(fabsf(wb->lo.z), fabsf(wb->hi.z)));
+                float pad = 1e-4f * fmaxf(fmaxf(fabsf(O.x), fabsf(O.y)), fmaxf(fabsf(O.z), sc));
+                if (!box_test(wb, O, inv, tmin, best->t, pad)) continue;
             }
             v3 Oo = xform_point(ci->inv, O), Do = xform_dir(ci->inv, D);
             trace_mesh(m, Oo, Do, tmin, f, i, use_bvh, best, st);

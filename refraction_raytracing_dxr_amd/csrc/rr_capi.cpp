@@ -40,6 +40,7 @@ struct MeshRes {
     NrmRec*   nrms = nullptr;
     bool      built = false;
     float     bounds[6] = { 0, 0, 0, 0, 0, 0 };
+    float     scale = 1.0f;          // max |bounds|
     uint32_t  depth = 0;
 };
 
@@ -72,6 +73,7 @@ struct rr_context {
     uint32_t n_insts = 0, tlas_depth = 0;
     bool tlas_built = false;
     bool single_identity = false;
+    float scene_scale = 1.0f;
 
     rr_scene_constants cam;
     bool cam_set = false;
@@ -198,12 +200,13 @@ void fill_scene(const rr_context* ctx, SceneDev& sc)
     if (ctx->single_identity) m0 = &ctx->meshes[(size_t)ctx->inst_host[0].blas];
     if (m0) {
         sc.blas0.nodes = m0->nodes; sc.blas0.tris = m0->tris; sc.blas0.nrms = m0->nrms;
-        sc.blas0.n_tris = m0->n_tris; sc.blas0.depth = m0->depth;
+        sc.blas0.n_tris = m0->n_tris; sc.blas0.depth = m0->depth; sc.blas0.scale = m0->scale;
     }
     sc.tlas_nodes = ctx->d_tlas;
     sc.insts = ctx->d_insts;
     sc.n_insts = ctx->n_insts;
     sc.single_identity = ctx->single_identity ? 1u : 0u;
+    sc.scale = ctx->scene_scale;
     sc.env = ctx->d_env;
     sc.env_w = ctx->env_w; sc.env_h = ctx->env_h;
 }
@@ -385,6 +388,8 @@ int rr_build_blas(rr_context* ctx, uint32_t mesh_id)
     RR_HIP(hipMemcpyAsync(&depth, s.b.depth, 4, hipMemcpyDeviceToHost, ctx->stream));
     RR_HIP(hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < 6; ++k) m.bounds[k] = ord2f_host(sb[k]);
+    m.scale = 0.0f;
+    for (int k = 0; k < 6; ++k) m.scale = std::max(m.scale, std::fabs(m.bounds[k]));
     m.depth = host_depth ? host_depth : depth;
     if (depth > 64) return fail(ctx, RR_ERR_UNSUPPORTED, "rr_build_blas: LBVH deeper than the 64-entry traversal stack");
     m.built = true;
@@ -402,6 +407,7 @@ int rr_build_tlas(rr_context* ctx, const rr_instance_desc* instances, uint32_t n
     }
     static const float ident[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
     std::vector<InstDev> host(n);
+    float scene_scale = 0.0f;
     std::vector<float> xb((size_t)n * 18);
     for (uint32_t i = 0; i < n; ++i) {
         const rr_instance_desc& d = instances[i];
@@ -416,6 +422,12 @@ int rr_build_tlas(rr_context* ctx, const rr_instance_desc* instances, uint32_t n
                 if (!std::isfinite(o.inv[k])) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_build_tlas: singular instance transform");
         }
         o.blas.nodes = m.nodes; o.blas.tris = m.tris; o.blas.nrms = m.nrms; o.blas.n_tris = m.n_tris; o.blas.depth = m.depth;
+        o.blas.scale = m.scale;
+        for (int c = 0; c < 8; ++c) {       // world-space extent of the instance (for the TLAS box padding)
+            const float x = (c & 1) ? m.bounds[3] : m.bounds[0], y = (c & 2) ? m.bounds[4] : m.bounds[1], z = (c & 4) ? m.bounds[5] : m.bounds[2];
+            for (int r = 0; r < 3; ++r)
+                scene_scale = std::max(scene_scale, std::fabs(d.transform[4 * r] * x + d.transform[4 * r + 1] * y + d.transform[4 * r + 2] * z + d.transform[4 * r + 3]));
+        }
         o.flags = d.hitgroup_flags >> 24;
         o.mask = d.instance_id_mask >> 24;
         memcpy(&xb[(size_t)i * 12], d.transform, 48);
@@ -446,6 +458,7 @@ int rr_build_tlas(rr_context* ctx, const rr_instance_desc* instances, uint32_t n
     if (e != hipSuccess) return fail(ctx, RR_ERR_DEVICE, "TLAS build", e);
     ctx->inst_host.assign(instances, instances + n);
     ctx->n_insts = n;
+    ctx->scene_scale = scene_scale;
     ctx->tlas_depth = depth;
     const rr_instance_desc& d0 = instances[0];
     ctx->single_identity = n == 1 && host[0].identity && (d0.hitgroup_flags >> 24) == 0 && ((d0.instance_id_mask >> 24) & 0xffu) != 0;

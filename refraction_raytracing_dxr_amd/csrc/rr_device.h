@@ -113,31 +113,37 @@ constexpr uint32_t CULL_BACK = 0x10u, CULL_FRONT = 0x20u;
 // box that holds a triangle the exact-order triangle test would accept).  Slabs are evaluated as
 // t = fma(plane, inv, -(O*inv)) with a hardware reciprocal; the rounding of that form
 // (<= |t|*2^-22 + |O*inv|*2^-24) is covered by moving the near planes earlier and the far planes later
-// by pad = |O*inv|*2^-22 + |inv|*1e-12 (i.e. the box grows by 1e-12 world units), folded into the
-// per-ray constants, plus a relative 2^-20 on t_far.  A (nearly) zero direction component gets
-// inv = +-1e20: pad is then >= 1e8, so the slab on that axis only rejects origins clearly outside
+// by pad = |O*inv|*2^-22 + |inv|*eps_w (i.e. the box grows by eps_w world units, see box_ray), folded
+// into the per-ray constants, plus a relative 2^-20 on t_far.  A (nearly) zero direction component
+// gets inv = +-1e20: pad is then huge, so the slab on that axis only rejects origins clearly outside
 // it -- rays lying exactly in a box face stay conservative.
 struct BoxRay {
     f3 inv;        // 1/D (approximate)
     f3 klo, khi;   // additive constants for the lo / hi planes: -(O*inv) -/+ sign(inv)*pad
 };
-__device__ __forceinline__ void box_axis(float o, float d, float& inv, float& klo, float& khi)
+__device__ __forceinline__ void box_axis(float o, float d, float eps_w, float& inv, float& klo, float& khi)
 {
     const float dg = fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d;
     inv = __builtin_amdgcn_rcpf(dg);
     const float oi = -(o * inv);
-    const float pad = copysignf(fmaf(fabsf(oi), 2.4e-7f, fabsf(inv) * 1e-12f), inv);
+    const float pad = copysignf(fmaf(fabsf(oi), 2.4e-7f, fabsf(inv) * eps_w), inv);
     klo = oi - pad;
     khi = oi + pad;
 }
-__device__ __forceinline__ BoxRay box_ray(f3 O, f3 D)
+// scene_scale: largest |coordinate| of the geometry the ray is traced against.  Boxes are grown by
+// 1e-5 of the larger of that and the ray origin's magnitude: the fp32 triangle test accepts points
+// a few ulps outside a triangle's edge (e.g. a ray running exactly along the symmetry plane of a
+// mirrored mesh, hitting the shared edges), and the box test must not cull those.
+__device__ __forceinline__ BoxRay box_ray(f3 O, f3 D, float scene_scale)
 {
+    const float eps_w = 1e-5f * fmaxf(fmaxf(fabsf(O.x), fabsf(O.y)), fmaxf(fabsf(O.z), scene_scale));
     BoxRay r;
-    box_axis(O.x, D.x, r.inv.x, r.klo.x, r.khi.x);
-    box_axis(O.y, D.y, r.inv.y, r.klo.y, r.khi.y);
-    box_axis(O.z, D.z, r.inv.z, r.klo.z, r.khi.z);
+    box_axis(O.x, D.x, eps_w, r.inv.x, r.klo.x, r.khi.x);
+    box_axis(O.y, D.y, eps_w, r.inv.y, r.klo.y, r.khi.y);
+    box_axis(O.z, D.z, eps_w, r.inv.z, r.klo.z, r.khi.z);
     return r;
 }
+
 constexpr int TRAV_DONE = (int)0x80000000;     // neither an internal index (>= 0) nor a leaf (~i with i < 2^31-1)
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -231,7 +237,7 @@ __device__ __forceinline__ void trace_blas(const BlasDev& bl, f3 O, f3 D, float 
                                            HitRec& best, uint32_t* stk, int sp0, uint32_t* err, TravCounters& cnt,
                                            const Diag dg = Diag{ nullptr })
 {
-    const BoxRay br = box_ray(O, D);
+    const BoxRay br = box_ray(O, D, bl.scale);
     const float4* __restrict__ nodes = reinterpret_cast<const float4*>(bl.nodes);
     int sp = sp0;
     int node = 0;
@@ -277,7 +283,7 @@ __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, floa
         return;
     }
     // two-level: the TLAS is a BVH2 of the same node type whose leaves are instance indices
-    const BoxRay br = box_ray(O, D);
+    const BoxRay br = box_ray(O, D, sc.scale);
     const float4* __restrict__ nodes = reinterpret_cast<const float4*>(sc.tlas_nodes);
     int sp = 0;
     int node = 0;

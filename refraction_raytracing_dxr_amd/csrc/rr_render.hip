@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_render_async(SceneDev sc, DispatchDev a
     uint32_t count = 0;
     bool outside = true;
     float tmin = a.tmin_p;
-    BoxRay br = box_ray(O, D);
+    BoxRay br = box_ray(O, D, sc.blas0.scale);
     HitRec h;
     h.t = a.tmax_p; h.hit = false; h.prim = 0; h.leaf = 0; h.inst = 0; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f;
     int node = 0, sp = 0;
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void k_render_async(SceneDev sc, DispatchDev a
                 }
                 if (have_next) {                                          // TraceRay(child, [1e-3, 1000])
                     tmin = a.tmin_s;
-                    br = box_ray(O, D);
+                    br = box_ray(O, D, sc.blas0.scale);
                     h.t = a.tmax_s; h.hit = false; h.prim = 0; h.leaf = 0; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f;
                     node = 0; sp = 0;
                 } else {                                                  // RenderTarget[xy] = float4(color,1)
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(1024) void k_render_lds(SceneDev sc, DispatchDev a,
         uint32_t count = 0;
         bool outside = true;
         float tmin = a.tmin_p;
-        BoxRay br = box_ray(O, D);
+        BoxRay br = box_ray(O, D, sc.blas0.scale);
         HitRec h;
         h.t = a.tmax_p; h.hit = false; h.prim = 0; h.leaf = 0; h.inst = 0; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f;
         int node = 0, sp = 0;
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(1024) void k_render_lds(SceneDev sc, DispatchDev a,
                     }
                     if (have_next) {
                         tmin = a.tmin_s;
-                        br = box_ray(O, D);
+                        br = box_ray(O, D, sc.blas0.scale);
                         h.t = a.tmax_s; h.hit = false; h.prim = 0; h.leaf = 0; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f;
                         node = 0; sp = 0;
                     } else {

@@ -43,6 +43,8 @@ struct BlasDev {
     const NrmRec*  nrms;
     uint32_t n_tris;
     uint32_t depth;
+    float    scale;           // largest |coordinate| of the mesh bounds (box-test padding)
+    uint32_t pad;
 };
 
 // instance record for two-level traversal (derived from the 64-byte rr_instance_desc)
@@ -61,6 +63,8 @@ struct SceneDev {
     const InstDev* insts;
     uint32_t n_insts;
     uint32_t single_identity; // 1: skip the top level entirely
+    float scale;              // largest |coordinate| of the world-space scene bounds
+    uint32_t pad0;
     const float4* env;        // w*h float4
     int32_t env_w, env_h;
 };

@@ -225,3 +225,15 @@ def test_path_weight_mode_is_within_rounding_of_recursion(env_hdr):
     b = s.render(M, cam, 128, 96, O.default_params(use_bvh=1, max_refract=8, accum_mode=1))
     assert np.allclose(a["rgb"], b["rgb"], rtol=2e-6, atol=1e-6)
     assert np.abs(a["rgba8"].astype(int) - b["rgba8"].astype(int)).max() <= 1
+
+
+@pytest.mark.parametrize("name", ["sphere.obj", "shell.obj", "cube.obj"])
+def test_bvh_equals_brute_force_on_the_symmetry_plane(name, env_png):
+    """odd frame height: the middle row's rays run exactly in the y = 0 mirror plane of these meshes and
+    hit shared edges; the padded box test must not cull what the triangle test accepts"""
+    s = _scene(name, env_png)
+    M, cam = O.camera(0.01)
+    a = s.render(M, cam, 120, 67, O.default_params(use_bvh=0, max_refract=8), want_rays=True)
+    b = s.render(M, cam, 120, 67, O.default_params(use_bvh=1, max_refract=8), want_rays=True)
+    assert np.array_equal(a["rays"], b["rays"])
+    assert np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
