@@ -22,8 +22,6 @@
 
 using namespace rr;
 
-namespace rr { uint32_t host_sah_build(const float* verts, const uint32_t* idx, uint32_t n_tris, std::vector<BvhNode>& nodes, std::vector<uint32_t>& order); }
-
 static_assert(sizeof(rr_vertex) == 32, "Vertex stride (Mesh.cpp:45)");
 static_assert(sizeof(rr_instance_desc) == 64, "D3D12_RAYTRACING_INSTANCE_DESC");
 static_assert(sizeof(rr_scene_constants) == 80, "SceneConstants");
@@ -367,21 +365,6 @@ int rr_build_blas(rr_context* ctx, uint32_t mesh_id)
     s.b.nodes = m.nodes;
     RR_HIP(launch_tri_setup(m.d_verts, m.d_idx, n, s.b, ctx->stream));
     RR_HIP(launch_lbvh(s.b, ctx->stream));
-    const char* dbg_bvh = getenv("RR_DEBUG_BVH");
-    uint32_t host_depth = 0;
-    if (dbg_bvh && !strcmp(dbg_bvh, "sah") && n > 1) {        // experiment: host full-sweep SAH hierarchy
-        std::vector<float> hv((size_t)m.n_verts * 8);
-        std::vector<uint32_t> hi(m.n_idx), order;
-        std::vector<BvhNode> hn;
-        RR_HIP(hipMemcpy(hv.data(), m.d_verts, hv.size() * 4, hipMemcpyDeviceToHost));
-        RR_HIP(hipMemcpy(hi.data(), m.d_idx, hi.size() * 4, hipMemcpyDeviceToHost));
-        host_depth = host_sah_build(hv.data(), hi.data(), n, hn, order);
-        std::vector<unsigned long long> keys(n);
-        for (uint32_t i = 0; i < n; ++i) keys[i] = order[i];
-        RR_HIP(hipStreamSynchronize(ctx->stream));
-        RR_HIP(hipMemcpy(s.b.keys, keys.data(), (size_t)n * 8, hipMemcpyHostToDevice));
-        RR_HIP(hipMemcpy(m.nodes, hn.data(), hn.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
-    }
     RR_HIP(launch_pack_tris(m.d_verts, m.d_idx, s.b, m.tris, m.nrms, ctx->stream));
     uint32_t sb[6], depth = 0;
     RR_HIP(hipMemcpyAsync(sb, s.b.scene_box, sizeof sb, hipMemcpyDeviceToHost, ctx->stream));
@@ -390,7 +373,7 @@ int rr_build_blas(rr_context* ctx, uint32_t mesh_id)
     for (int k = 0; k < 6; ++k) m.bounds[k] = ord2f_host(sb[k]);
     m.scale = 0.0f;
     for (int k = 0; k < 6; ++k) m.scale = std::max(m.scale, std::fabs(m.bounds[k]));
-    m.depth = host_depth ? host_depth : depth;
+    m.depth = depth;
     if (depth > 64) return fail(ctx, RR_ERR_UNSUPPORTED, "rr_build_blas: LBVH deeper than the 64-entry traversal stack");
     m.built = true;
     ctx->tlas_built = false;      // any TLAS built before refers to the old BLAS
@@ -600,12 +583,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     }
     int stack_sel = need <= 16 ? 16 : need <= 24 ? 24 : need <= 32 ? 32 : 64;
     if (const char* ov = getenv("RR_DEBUG_STACK")) stack_sel = atoi(ov);   // experiments only
-    LdsPlan plan;
-    const MeshRes* m0 = ctx->single_identity ? &ctx->meshes[(size_t)ctx->inst_host[0].blas] : nullptr;
-    if (!a.diag && m0 && plan_render_lds(sc, a, m0->n_tris > 1 ? m0->n_tris - 1 : 1, m0->depth, p.max_reflect <= 2 ? 2 : 8, plan))
-        RR_HIP(launch_render_lds(sc, a, plan, stats, ctx->n_cus, ctx->stream));
-    else
-        RR_HIP(launch_render_fused(sc, a, stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream));
+    RR_HIP(launch_render_fused(sc, a, stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream));
     if (timed) {
         RR_HIP(hipEventRecord(ctx->kev[(size_t)ctx->kev_used * 2 + 1], ctx->stream));
         ++ctx->kev_used;

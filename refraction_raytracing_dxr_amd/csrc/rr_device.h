@@ -169,11 +169,24 @@ __device__ __forceinline__ void box2_hit(const BoxRay& r, const float4 q0, const
     h1 = tn1 <= tf1 * 1.000001f;
 }
 
+// per-lane traversal stack in LDS, column layout (entry e of lane l at base[e*64 + l]: conflict-free)
+struct Stack32 {
+    uint32_t* p;
+    __device__ __forceinline__ void push(int sp, int v) const { p[sp * 64] = (uint32_t)v; }
+    __device__ __forceinline__ int pop(int sp) const { return (int)p[sp * 64]; }
+};
+// 16-bit entries (half the LDS) for BVHs with < 32768 nodes and leaves: internal i -> i, leaf ~l -> 0x8000 | l
+struct Stack16 {
+    uint16_t* p;
+    __device__ __forceinline__ void push(int sp, int v) const { p[sp * 64] = v >= 0 ? (uint16_t)v : (uint16_t)(0x8000u | (uint32_t)~v); }
+    __device__ __forceinline__ int pop(int sp) const { const uint32_t u = p[sp * 64]; return (u & 0x8000u) ? ~(int)(u & 0x7fffu) : (int)u; }
+};
+
 // one traversal step at an internal node: returns the next node (near child, or a popped entry, or
 // TRAV_DONE) and pushes the far child when both are hit.  stk: this lane's LDS column, sp0: stack floor.
-template <bool CHECK>
+template <bool CHECK, class StackT>
 __device__ __forceinline__ int node_step(const BoxRay& br, const float4 q0, const float4 q1, const float4 q2, const float4 q3,
-                                         float tmin, float tmax, uint32_t* stk, int& sp, int sp0, int cap, uint32_t& err)
+                                         float tmin, float tmax, const StackT stk, int& sp, int sp0, int cap, uint32_t& err)
 {
     bool h0, h1;
     float tn0, tn1;
@@ -183,9 +196,9 @@ __device__ __forceinline__ int node_step(const BoxRay& br, const float4 q0, cons
     const int nearc = (h0 && !(h1 && swap)) ? c0 : c1;
     int next = (h0 || h1) ? nearc : TRAV_DONE;
     if (both) {
-        if (!CHECK || sp < cap) { stk[sp * 64] = (uint32_t)(swap ? c0 : c1); ++sp; } else err = 1u;
+        if (!CHECK || sp < cap) { stk.push(sp, swap ? c0 : c1); ++sp; } else err = 1u;
     }
-    if (!(h0 || h1) && sp > sp0) { --sp; next = (int)stk[sp * 64]; }
+    if (!(h0 || h1) && sp > sp0) { --sp; next = stk.pop(sp); }
     return next;
 }
 
@@ -232,9 +245,9 @@ __device__ __forceinline__ void tri_test(const TriRec* __restrict__ tris, uint32
 // "while-while" form: all lanes first descend internal nodes (near child first, far child pushed)
 // until every lane of the wave holds a leaf or has finished; only then is the (expensive) triangle
 // test executed, once, for all lanes that hold a leaf.
-template <int STACK, bool STATS>
+template <int STACK, bool STATS, class StackT = Stack32>
 __device__ __forceinline__ void trace_blas(const BlasDev& bl, f3 O, f3 D, float tmin, uint32_t cull, uint32_t inst,
-                                           HitRec& best, uint32_t* stk, int sp0, uint32_t* err, TravCounters& cnt,
+                                           HitRec& best, const StackT stk, int sp0, uint32_t* err, TravCounters& cnt,
                                            const Diag dg = Diag{ nullptr })
 {
     const BoxRay br = box_ray(O, D, bl.scale);
@@ -253,7 +266,7 @@ __device__ __forceinline__ void trace_blas(const BlasDev& bl, f3 O, f3 D, float 
         diag_trip(dg);
         if (STATS) cnt.tris++;
         tri_test(bl.tris, (uint32_t)~node, O, D, tmin, cull, inst, best);
-        if (sp > sp0) { --sp; node = (int)stk[sp * 64]; } else node = TRAV_DONE;
+        if (sp > sp0) { --sp; node = stk.pop(sp); } else node = TRAV_DONE;
     }
 }
 
@@ -279,7 +292,7 @@ __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, floa
     best.t = tmax; best.hit = false; best.prim = 0; best.leaf = 0; best.inst = 0; best.U = 0.0f; best.V = 0.0f;
     best.ad = 1.0f;
     if (!TLAS) {      // the reference's scene: one identity instance, mask 1, flags 0 (RefractionDemo.cpp:324-334)
-        trace_blas<STACK, STATS>(sc.blas0, O, D, tmin, flags, 0u, best, stk, 0, err, cnt, dg);
+        trace_blas<STACK, STATS>(sc.blas0, O, D, tmin, flags, 0u, best, Stack32{ stk }, 0, err, cnt, dg);
         return;
     }
     // two-level: the TLAS is a BVH2 of the same node type whose leaves are instance indices
@@ -297,7 +310,7 @@ __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, floa
             const float4 g0 = make_float4(q0.x - g * fabsf(q0.x), q0.y - g * fabsf(q0.y), q0.z - g * fabsf(q0.z), q0.w - g * fabsf(q0.w));
             const float4 g1 = make_float4(q1.x - g * fabsf(q1.x), q1.y - g * fabsf(q1.y), q1.z + g * fabsf(q1.z), q1.w + g * fabsf(q1.w));
             const float4 g2 = make_float4(q2.x + g * fabsf(q2.x), q2.y + g * fabsf(q2.y), q2.z + g * fabsf(q2.z), q2.w + g * fabsf(q2.w));
-            node = node_step<true>(br, g0, g1, g2, q3, tmin, best.t, stk, sp, 0, STACK, *err);
+            node = node_step<true>(br, g0, g1, g2, q3, tmin, best.t, Stack32{ stk }, sp, 0, STACK, *err);
         }
         if (node == TRAV_DONE) break;
         {
@@ -312,7 +325,7 @@ __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, floa
                 }
                 f3 Oo = O, Do = D;
                 if (!in.identity) { Oo = xform_point(in.inv, O); Do = xform_dir(in.inv, D); }
-                trace_blas<STACK, STATS>(in.blas, Oo, Do, tmin, f, ii, best, stk, sp, err, cnt);
+                trace_blas<STACK, STATS>(in.blas, Oo, Do, tmin, f, ii, best, Stack32{ stk }, sp, err, cnt);
             }
         }
         if (sp > 0) { --sp; node = (int)stk[sp * 64]; } else node = TRAV_DONE;

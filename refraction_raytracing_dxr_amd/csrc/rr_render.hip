@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void k_render_async(SceneDev sc, DispatchDev a
                 const float4* q = nodes + (uint32_t)node * 4u;
                 const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
                 if (STATS) ++n_nodes;
-                node = node_step<true>(br, q0, q1, q2, q3, tmin, h.t, stk, sp, 0, STACK, err);
+                node = node_step<true>(br, q0, q1, q2, q3, tmin, h.t, Stack32{ stk }, sp, 0, STACK, err);
             }
         } else if (nL >= nS) {
             // ---- triangle step ------------------------------------------------------------------------
@@ -358,168 +358,6 @@ __global__ __launch_bounds__(256) void k_render_async(SceneDev sc, DispatchDev a
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// LDS-resident form.  Measured on MI355X, the global-memory kernels above are bound by the per-CU L1
-// (TCP) request rate: every node visit of a divergent wave is 64 lanes x 4 separate 16-byte requests
-// (293 M requests per 1080p monkey frame ~ 1.1 M per CU at ~1 request/clk).  The reference's meshes
-// are tiny (monkey.obj: 966 nodes = 60 KiB), so each workgroup copies the whole node array into LDS
-// once and traverses from there (ds_read_b128, ~10x the divergent-request rate of the L1); triangle,
-// normal and env-map records stay in global memory (they are ~10 % of the requests).
-// Persistent: one workgroup per CU loops over 8x8-pixel patches; consecutive patches go to
-// consecutive workgroups so a heavy 32x32 tile is spread over 16 CUs.  Same lane-asynchronous state
-// machine and same arithmetic as k_render_async: results are bit-identical.
-template <int PEND, bool STATS>
-__global__ __launch_bounds__(1024) void k_render_lds(SceneDev sc, DispatchDev a, LdsPlan plan)
-{
-    extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    {   // stage the BVH nodes
-        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(sc.blas0.nodes);
-        const uint32_t n4 = plan.n_nodes * 4u;
-        for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) lds4[i] = src[i];
-    }
-    __syncthreads();
-    const float4* nodes = reinterpret_cast<const float4*>(lds4);
-    uint32_t* stk = reinterpret_cast<uint32_t*>(lds4 + plan.n_nodes * 4u) + wave * (plan.stack_cap * 64u) + lane;
-    const int stack_cap = (int)plan.stack_cap;
-
-    uint32_t n_rays = 0, n_hits = 0, n_miss = 0, n_term = 0, n_tir = 0, n_nodes = 0, n_tris = 0, n_prim = 0;
-    uint32_t err = 0;
-    const uint32_t lx = compact1by1(lane), ly = compact1by1(lane >> 1);
-
-    for (uint32_t g = wave * gridDim.x + blockIdx.x; g < plan.n_wave_tiles; g += gridDim.x * plan.waves) {
-        const uint32_t tile_local = g >> 4, sub = g & 15u;
-        const uint32_t tile = tile_local * a.tile_world + a.tile_rank;
-        const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-        const uint32_t px = (sub & 3u) * 8u + lx, py = (sub >> 2) * 8u + ly;
-        const uint32_t x = tx * TILE + px, y = ty * TILE + py;
-        const bool valid = x < a.W && y < a.H;
-        if (STATS && valid) ++n_prim;
-
-        bool alive = valid;
-        f3 acc = mk3(0.0f, 0.0f, 0.0f);
-        PendRay pend[PEND];
-        int np = 0;
-        const CamDev& cb = a.cams[0];
-        f3 O = mk3(cb.cam[0], cb.cam[1], cb.cam[2]);
-        f3 D = valid ? camera_ray_dir(cb.M, x, y, a.W, a.H) : mk3(1.0f, 0.0f, 0.0f);
-        float w = 1.0f;
-        uint32_t count = 0;
-        bool outside = true;
-        float tmin = a.tmin_p;
-        BoxRay br = box_ray(O, D, sc.blas0.scale);
-        HitRec h;
-        h.t = a.tmax_p; h.hit = false; h.prim = 0; h.leaf = 0; h.inst = 0; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f;
-        int node = 0, sp = 0;
-
-        for (;;) {
-            const bool wantI = alive && node >= 0;
-            const bool wantL = alive && node < 0 && node != TRAV_DONE;
-            const bool wantS = alive && node == TRAV_DONE;
-            const unsigned long long mI = __ballot(wantI), mL = __ballot(wantL), mS = __ballot(wantS);
-            if ((mI | mL | mS) == 0ull) break;
-            const int nI = __popcll(mI), nL = __popcll(mL), nS = __popcll(mS);
-            if (nI >= nL && nI >= nS) {
-                if (wantI) {
-                    const float4* q = nodes + (uint32_t)node * 4u;
-                    const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-                    if (STATS) ++n_nodes;
-                    node = node_step<true>(br, q0, q1, q2, q3, tmin, h.t, stk, sp, 0, stack_cap, err);
-                }
-            } else if (nL >= nS) {
-                if (wantL) {
-                    if (STATS) ++n_tris;
-                    tri_test(sc.blas0.tris, (uint32_t)~node, O, D, tmin, outside ? CULL_BACK : CULL_FRONT, 0u, h);
-                    if (sp > 0) { --sp; node = (int)stk[sp * 64]; } else node = TRAV_DONE;
-                }
-            } else {
-                if (wantS) {
-                    ++n_rays;
-                    bool have_next = false;
-                    if (!h.hit) {
-                        if (STATS) ++n_miss;
-                        const f3 e = env_lookup(sc, D);
-                        acc.x = fmaf(w, e.x, acc.x); acc.y = fmaf(w, e.y, acc.y); acc.z = fmaf(w, e.z, acc.z);
-                    } else {
-                        if (STATS) ++n_hits;
-                        if ((int)count < a.max_refract) {
-                            const f3 N = shading_normal<false>(sc, h);
-                            const f3 X = mk3(fmaf(h.t, D.x, O.x), fmaf(h.t, D.y, O.y), fmaf(h.t, D.z, O.z));
-                            const f3 Nf = outside ? N : neg3(N);
-                            const float R0 = (0.2f / 2.2f) * (0.2f / 2.2f);
-                            const float b = 1.0f - dot3(D, Nf);
-                            const float b2 = b * b, b4 = b2 * b2;
-                            const float R = (R0 * (1.0f - R0)) * (b4 * b);
-                            const float eta = outside ? a.inv_ior : a.ior;
-                            f3 d1;
-                            const bool refr = refract_ray(d1, D, Nf, eta);
-                            if (STATS && !refr) ++n_tir;
-                            const bool refl = (int)count < a.max_reflect;
-                            f3 d2 = mk3(0.0f, 0.0f, 0.0f);
-                            if (refl) d2 = normalize3(reflect_ray(D, Nf));
-                            const uint32_t c1 = count + 1u;
-                            O = X;
-                            if (refr) {
-                                if (refl) {
-                                    PendRay p;
-                                    p.ox = X.x; p.oy = X.y; p.oz = X.z; p.dx = d2.x; p.dy = d2.y; p.dz = d2.z;
-                                    p.w = w * R; p.meta = c1 | (outside ? 0x10000u : 0u);
-#pragma unroll
-                                    for (int k = 0; k < PEND; ++k) if (k == np) pend[k] = p;
-                                    ++np;
-                                }
-                                D = d1; w = w * (1.0f - R); count = c1; outside = !outside;
-                                have_next = true;
-                            } else if (refl) {
-                                D = d2; w = w * R; count = c1;
-                                have_next = true;
-                            }
-                        } else if (STATS) {
-                            ++n_term;
-                        }
-                    }
-                    if (!have_next && np > 0) {
-                        --np;
-                        PendRay p = pend[0];
-#pragma unroll
-                        for (int k = 1; k < PEND; ++k) if (k == np) p = pend[k];
-                        O = mk3(p.ox, p.oy, p.oz); D = mk3(p.dx, p.dy, p.dz); w = p.w;
-                        count = p.meta & 0xffffu; outside = (p.meta & 0x10000u) != 0u;
-                        have_next = true;
-                    }
-                    if (have_next) {
-                        tmin = a.tmin_s;
-                        br = box_ray(O, D, sc.blas0.scale);
-                        h.t = a.tmax_s; h.hit = false; h.prim = 0; h.leaf = 0; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f;
-                        node = 0; sp = 0;
-                    } else {
-                        const uint32_t packed = unorm8(acc.x) | (unorm8(acc.y) << 8) | (unorm8(acc.z) << 16) | 0xff000000u;
-                        const size_t o = a.compact_out == 0u ? (size_t)y * a.W + x
-                                                             : (size_t)tile_local * (TILE * TILE) + py * TILE + px;
-                        a.out_rgba8[o] = packed;
-                        if (a.out_f32) a.out_f32[o] = make_float4(acc.x, acc.y, acc.z, 1.0f);
-                        alive = false;
-                    }
-                }
-            }
-        }
-    }
-
-    uint32_t wr = wave_reduce_add(n_rays);
-    if (lane == 0 && wr) atomicAdd(&a.ray_shards[(blockIdx.x * 16u + wave) & (RAY_SHARDS - 1)], wr);
-    if (err) atomicOr(a.error_flag, 1u);
-    if (STATS) {
-        uint32_t v;
-        v = wave_reduce_add(n_hits);  if (lane == 0 && v) atomicAdd(&a.counters[C_HITS], (unsigned long long)v);
-        v = wave_reduce_add(n_miss);  if (lane == 0 && v) atomicAdd(&a.counters[C_MISSES], (unsigned long long)v);
-        v = wave_reduce_add(n_term);  if (lane == 0 && v) atomicAdd(&a.counters[C_TERMINAL], (unsigned long long)v);
-        v = wave_reduce_add(n_tir);   if (lane == 0 && v) atomicAdd(&a.counters[C_TIR], (unsigned long long)v);
-        v = wave_reduce_add(n_nodes); if (lane == 0 && v) atomicAdd(&a.counters[C_NODES], (unsigned long long)v);
-        v = wave_reduce_add(n_tris);  if (lane == 0 && v) atomicAdd(&a.counters[C_TRIS], (unsigned long long)v);
-        v = wave_reduce_add(n_prim);  if (lane == 0 && v) atomicAdd(&a.counters[C_PRIMARY], (unsigned long long)v);
-    }
-}
-
 // TraceRay in isolation, for the parity tests (rr_trace_rays)
 template <int STACK, bool TLAS>
 __global__ __launch_bounds__(256) void k_trace_rays(SceneDev sc, const rr_ray_dev* rays, uint32_t n, rr_hit_dev* hits,
@@ -597,11 +435,17 @@ static hipError_t launch_async_sp(const SceneDev& sc, const DispatchDev& a, bool
 
 // default: the lock-step kernel (best throughput once several slices are in flight); RR_DEBUG_KERNEL=async
 // selects the lane-asynchronous one (shorter worst wave on irregular meshes, costlier trips)
-static bool use_sync_kernel()
+
+static int kernel_choice()      // 1 lock-step (default), 2 lane-asynchronous
 {
-    static const bool v = [] { const char* e = getenv("RR_DEBUG_KERNEL"); return !(e && !strcmp(e, "async")); }();
+    static const int v = [] {
+        const char* e = getenv("RR_DEBUG_KERNEL");
+        return (e && !strcmp(e, "async")) ? 2 : 1;
+    }();
     return v;
 }
+
+static bool use_sync_kernel() { return kernel_choice() != 2; }
 
 template <int STACK, int PEND>
 static hipError_t launch_fused_sp(const SceneDev& sc, const DispatchDev& a, bool stats, hipStream_t s)
@@ -609,42 +453,6 @@ static hipError_t launch_fused_sp(const SceneDev& sc, const DispatchDev& a, bool
     if (!sc.single_identity) return launch_fused_spt<STACK, PEND, true>(sc, a, stats, s);
     if (use_sync_kernel()) return launch_fused_spt<STACK, PEND, false>(sc, a, stats, s);
     return launch_async_sp<STACK, PEND>(sc, a, stats, s);
-}
-
-// LDS budget of one CU that a single workgroup may claim (160 KiB), and what k_render_lds needs
-static constexpr size_t LDS_PER_CU = 160u * 1024u;
-
-bool plan_render_lds(const SceneDev& sc, const DispatchDev& a, uint32_t n_nodes, uint32_t depth, int pend, LdsPlan& plan)
-{
-    static const bool on = [] { const char* e = getenv("RR_DEBUG_KERNEL"); return e && !strcmp(e, "lds"); }();   // experiments only
-    if (!on || !sc.single_identity || pend > 2 || a.n_frames != 1) return false;
-    const size_t node_bytes = (size_t)n_nodes * sizeof(BvhNode);
-    const uint32_t cap = (depth + 3u) & ~3u;
-    if (node_bytes >= LDS_PER_CU) return false;
-    uint32_t waves = (uint32_t)((LDS_PER_CU - node_bytes) / ((size_t)cap * 256u));
-    if (waves > 16u) waves = 16u;
-    if (waves < 8u) return false;                 // too little latency hiding: use the global-memory kernel
-    plan.n_nodes = n_nodes; plan.stack_cap = cap; plan.waves = waves; plan.n_wave_tiles = a.n_local_tiles * 16u;
-    return true;
-}
-
-hipError_t launch_render_lds(const SceneDev& sc, const DispatchDev& a, const LdsPlan& plan, bool stats, int n_cus, hipStream_t s)
-{
-    if (plan.n_wave_tiles == 0) return hipSuccess;
-    const size_t lds = (size_t)plan.n_nodes * sizeof(BvhNode) + (size_t)plan.waves * plan.stack_cap * 256u;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_render_lds<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_PER_CU);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_render_lds<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_PER_CU);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    uint32_t blocks = (uint32_t)n_cus;
-    const uint32_t need = (plan.n_wave_tiles + plan.waves - 1u) / plan.waves;
-    if (blocks > need) blocks = need;
-    if (stats) hipLaunchKernelGGL((k_render_lds<2, true>), dim3(blocks), dim3(plan.waves * 64u), lds, s, sc, a, plan);
-    else       hipLaunchKernelGGL((k_render_lds<2, false>), dim3(blocks), dim3(plan.waves * 64u), lds, s, sc, a, plan);
-    return hipGetLastError();
 }
 
 hipError_t launch_render_fused(const SceneDev& sc, const DispatchDev& a, int stack, int pend, bool stats, hipStream_t s)

@@ -97,14 +97,6 @@ struct DispatchDev {
     unsigned long long* diag;       // diagnostic builds only: 4 x u64 per wave {start, cycles, rays(max lane), loop trips}
 };
 
-// geometry of the LDS-resident persistent kernel (k_render_lds)
-struct LdsPlan {
-    uint32_t n_nodes;          // BvhNode records copied into LDS by every block
-    uint32_t stack_cap;        // traversal stack entries per lane
-    uint32_t waves;            // waves per block
-    uint32_t n_wave_tiles;     // 8x8-pixel patches this rank renders (16 per local 32x32 tile)
-};
-
 enum Counter : int {
     C_RAYS = 0, C_PRIMARY, C_SECONDARY, C_HITS, C_MISSES, C_TERMINAL, C_TIR, C_NODES, C_TRIS, C_COUNT
 };
