@@ -85,11 +85,11 @@ def cpu_baseline(mesh, env, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=384)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--depth1", action="store_true", help="also time the reference's shape, one DispatchRays per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--frames-per-dispatch", type=int, default=16,
+    ap.add_argument("--frames-per-dispatch", type=int, default=64,
                     help="depth slices per launch (DispatchRays(W,H,Depth)); N>1: also frames per RCCL gather")
     args = ap.parse_args()
 
@@ -107,11 +107,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if os.environ.get("RR_BENCH_BACKEND", "nccl") != "nccl":
+        local_rank = 0                      # rehearsal: every rank shares the one card
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("RR_BENCH_BACKEND", "nccl")      # "gloo" only to rehearse the N>1 path on a 1-GPU box
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     mesh = rr.Mesh()
     assert mesh.load(O.asset("monkey.obj"))
