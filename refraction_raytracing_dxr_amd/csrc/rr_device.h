@@ -203,10 +203,10 @@ __device__ __forceinline__ int node_step(const BoxRay& br, const float4 q0, cons
 }
 
 // diagnostic builds count wave-level loop trips in LDS (one word per wave); null in product builds
-struct Diag { uint32_t* trips; };
-__device__ __forceinline__ void diag_trip(const Diag& d)
+struct Diag { uint32_t* trips; };      // trips[0]: internal-node trips, trips[4]: leaf trips (one word per wave each)
+__device__ __forceinline__ void diag_trip(const Diag& d, int which = 0)
 {
-    if (d.trips) { const unsigned long long m = __ballot(1); if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) *d.trips += 1u; }
+    if (d.trips) { const unsigned long long m = __ballot(1); if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) d.trips[which * 4] += 1u; }
 }
 
 
@@ -263,7 +263,7 @@ __device__ __forceinline__ void trace_blas(const BlasDev& bl, f3 O, f3 D, float 
             node = node_step<true>(br, q0, q1, q2, q3, tmin, best.t, stk, sp, sp0, STACK, *err);
         }
         if (node == TRAV_DONE) break;
-        diag_trip(dg);
+        diag_trip(dg, 1);
         if (STATS) cnt.tris++;
         tri_test(bl.tris, (uint32_t)~node, O, D, tmin, cull, inst, best);
         if (sp > sp0) { --sp; node = stk.pop(sp); } else node = TRAV_DONE;

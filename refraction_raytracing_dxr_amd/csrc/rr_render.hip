@@ -49,9 +49,9 @@ __device__ __forceinline__ void block_to_tile(uint32_t b, uint32_t& tile_local, 
 template <int STACK, int PEND, bool STATS, bool TLAS, bool DIAG = false>
 __global__ __launch_bounds__(256, RR_FUSED_WAVES_PER_SIMD) void k_render_fused(SceneDev sc, DispatchDev a)
 {
-    __shared__ uint32_t diag_trips[4];
+    __shared__ uint32_t diag_trips[12];    // per wave: internal trips, leaf trips, shading passes
     const unsigned long long diag_t0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
-    if (DIAG && threadIdx.x < 4) diag_trips[threadIdx.x] = 0;
+    if (DIAG && threadIdx.x < 12) diag_trips[threadIdx.x] = 0;
     if (DIAG) __syncthreads();
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256, RR_FUSED_WAVES_PER_SIMD) void k_render_fused(S
             trace_scene<STACK, STATS, TLAS>(sc, O, D, tmin, tmax, outside ? CULL_BACK : CULL_FRONT, h, stk, &err, cnt,
                                             Diag{ DIAG ? &diag_trips[threadIdx.x >> 6] : nullptr });
             ++n_rays;
+            if (DIAG) diag_trip(Diag{ &diag_trips[threadIdx.x >> 6] }, 2);
             bool have_next = false;
             if (!h.hit) {                                             // Miss
                 if (STATS) ++n_miss;
@@ -162,7 +163,8 @@ __global__ __launch_bounds__(256, RR_FUSED_WAVES_PER_SIMD) void k_render_fused(S
         for (int off = 32; off > 0; off >>= 1) { uint32_t v = __shfl_xor(mx, off, 64); mx = v > mx ? v : mx; }
         if (lane == 0) {
             unsigned long long* d = a.diag + (size_t)(blockIdx.x * 4u + wave) * 4;
-            d[0] = diag_t0; d[1] = __builtin_amdgcn_s_memtime() - diag_t0; d[2] = mx; d[3] = diag_trips[wave];
+            d[0] = ((unsigned long long)diag_trips[8 + wave] << 40) | ((unsigned long long)diag_trips[4 + wave] << 20) | diag_trips[wave];
+            d[1] = __builtin_amdgcn_s_memtime() - diag_t0; d[2] = mx; d[3] = diag_trips[wave] + diag_trips[4 + wave];
         }
     }
     // ray count: one sharded add per wave
