@@ -229,6 +229,13 @@ int  rr_host_camera_orbit(float angle, float fov_y, float aspect, float zn, floa
  * be opened returns RR_ERR_IO (Mesh::load returns false). */
 int  rr_host_mesh_load_obj(const char* filename, rr_vertex** verts, uint32_t* n_verts,
                            uint32_t** indices, uint32_t* n_indices);
+/* Additive hardening behind the same output format: with RR_OBJ_HARDENED faces may be
+ * polygons (fan-triangulated), corners may be "v", "v/vt", "v//vn" or "v/vt/vn", indices may be
+ * negative; a missing uv is (0,0), a face without normals gets its flat winding normal.
+ * flags = 0 is exactly rr_host_mesh_load_obj. */
+#define RR_OBJ_HARDENED 0x1u
+int  rr_host_mesh_load_obj_ex(const char* filename, uint32_t flags, rr_vertex** verts, uint32_t* n_verts,
+                              uint32_t** indices, uint32_t* n_indices);
 /* stbi_loadf(file,&x,&y,&n,req_comp) as called at RefractionDemo.cpp:111: Radiance .hdr and .png
  * (8/16-bit, non-interlaced), LDR expanded with pow(v/255, 2.2).  NULL on failure. */
 float* rr_host_image_loadf(const char* filename, int* x, int* y, int* channels_in_file, int req_comp);

@@ -93,6 +93,8 @@ SYMBOLS = {
     "rr_host_camera_orbit": (C.c_int, [C.c_float] * 5 + [C.POINTER(SceneConstants)]),
     "rr_host_mesh_load_obj": (C.c_int, [C.c_char_p, C.POINTER(_P), C.POINTER(C.c_uint32), C.POINTER(_P),
                                         C.POINTER(C.c_uint32)]),
+    "rr_host_mesh_load_obj_ex": (C.c_int, [C.c_char_p, C.c_uint32, C.POINTER(_P), C.POINTER(C.c_uint32), C.POINTER(_P),
+                                           C.POINTER(C.c_uint32)]),
     "rr_host_image_loadf": (_P, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
     "rr_host_image_write_hdr": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _P]),
     "rr_host_free": (None, [_P]),

@@ -8,6 +8,7 @@
 #include "../../../include/rrdxr.h"
 
 #include <cerrno>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -65,10 +66,55 @@ bool scan_face(const char* line, int ref[9])
 
 } // namespace
 
+// Generic face record for the hardened mode: any number of corners, each "v", "v/vt", "v//vn" or
+// "v/vt/vn", indices may be negative (relative to the end of the pools read so far).
+struct Corner { long v, vt, vn; };
+
+static bool scan_face_any(const char* line, std::vector<Corner>& out)
+{
+    out.clear();
+    const char* p = line;
+    if (*p != 'f' || !(p[1] == ' ' || p[1] == '\t')) return false;
+    ++p;
+    for (;;) {
+        while (*p == ' ' || *p == '\t' || *p == '\r') ++p;
+        if (!*p) break;
+        Corner c{ 0, 0, 0 };
+        char* end = nullptr;
+        c.v = strtol(p, &end, 10);
+        if (end == p) return false;
+        p = end;
+        if (*p == '/') {
+            ++p;
+            if (*p != '/') { c.vt = strtol(p, &end, 10); if (end == p) return false; p = end; }
+            if (*p == '/') { ++p; c.vn = strtol(p, &end, 10); if (end == p) return false; p = end; }
+        }
+        out.push_back(c);
+    }
+    return out.size() >= 3;
+}
+
+static int load_obj_impl(const char* filename, uint32_t flags, rr_vertex** verts, uint32_t* n_verts, uint32_t** indices,
+                         uint32_t* n_indices);
+
 extern "C" int rr_host_mesh_load_obj(const char* filename, rr_vertex** verts, uint32_t* n_verts, uint32_t** indices,
                                      uint32_t* n_indices)
 {
+    return load_obj_impl(filename, 0u, verts, n_verts, indices, n_indices);
+}
+
+extern "C" int rr_host_mesh_load_obj_ex(const char* filename, uint32_t flags, rr_vertex** verts, uint32_t* n_verts,
+                                        uint32_t** indices, uint32_t* n_indices)
+{
+    return load_obj_impl(filename, flags, verts, n_verts, indices, n_indices);
+}
+
+static int load_obj_impl(const char* filename, uint32_t flags, rr_vertex** verts, uint32_t* n_verts, uint32_t** indices,
+                         uint32_t* n_indices)
+{
     if (!filename || !verts || !n_verts || !indices || !n_indices) return RR_ERR_INVALID_ARGUMENT;
+    const bool hardened = (flags & RR_OBJ_HARDENED) != 0;
+    std::vector<Corner> poly;
     *verts = nullptr; *indices = nullptr; *n_verts = 0; *n_indices = 0;
     FILE* f = fopen(filename, "rb");
     if (!f) return RR_ERR_IO;                       // Mesh.cpp:9-10: load() returns false
@@ -88,7 +134,35 @@ extern "C" int rr_host_mesh_load_obj(const char* filename, rr_vertex** verts, ui
         if (scan_reals(l, "v", 3, v)) pos.insert(pos.end(), v, v + 3);
         else if (scan_reals(l, "vt", 2, v)) tex.insert(tex.end(), v, v + 2);
         else if (scan_reals(l, "vn", 3, v)) nrm.insert(nrm.end(), v, v + 3);
-        else if (scan_face(l, ref)) {
+        else if (hardened && scan_face_any(l, poly)) {
+            // resolve negative / missing references, fan-triangulate, synthesise what is missing
+            const long np = (long)pos.size() / 3, nt = (long)tex.size() / 2, nn = (long)nrm.size() / 3;
+            std::vector<rr_vertex> cv(poly.size());
+            bool have_n = true;
+            for (size_t c = 0; c < poly.size(); ++c) {
+                long a = poly[c].v < 0 ? np + poly[c].v + 1 : poly[c].v;
+                long b = poly[c].vt < 0 ? nt + poly[c].vt + 1 : poly[c].vt;
+                long n = poly[c].vn < 0 ? nn + poly[c].vn + 1 : poly[c].vn;
+                if (a < 1 || a > np || b < 0 || b > nt || n < 0 || n > nn) { fclose(f); return RR_ERR_INVALID_ARGUMENT; }
+                std::memset(&cv[c], 0, sizeof(rr_vertex));
+                std::memcpy(cv[c].position, &pos[(size_t)(a - 1) * 3], 12);
+                if (b) std::memcpy(cv[c].uv, &tex[(size_t)(b - 1) * 2], 8);
+                if (n) std::memcpy(cv[c].norm, &nrm[(size_t)(n - 1) * 3], 12); else have_n = false;
+            }
+            for (size_t c = 1; c + 1 < poly.size(); ++c) {
+                rr_vertex tri[3] = { cv[0], cv[c], cv[c + 1] };
+                if (!have_n) {                 // flat normal on the side the winding faces (cross(e1,e2))
+                    float e1[3], e2[3], g[3];
+                    for (int k = 0; k < 3; ++k) { e1[k] = tri[1].position[k] - tri[0].position[k]; e2[k] = tri[2].position[k] - tri[0].position[k]; }
+                    g[0] = e1[1] * e2[2] - e1[2] * e2[1]; g[1] = e1[2] * e2[0] - e1[0] * e2[2]; g[2] = e1[0] * e2[1] - e1[1] * e2[0];
+                    float len = std::sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+                    if (len > 0.0f) for (int k = 0; k < 3; ++k) g[k] /= len;
+                    for (int q = 0; q < 3; ++q) std::memcpy(tri[q].norm, g, 12);
+                }
+                out.insert(out.end(), tri, tri + 3);
+            }
+        }
+        else if (!hardened && scan_face(l, ref)) {
             for (int c = 0; c < 3; ++c) {
                 const long a = ref[c * 3 + 0], b = ref[c * 3 + 1], n = ref[c * 3 + 2];   // 1-based
                 if (a < 1 || (size_t)a * 3 > pos.size() || b < 1 || (size_t)b * 2 > tex.size() || n < 1 ||

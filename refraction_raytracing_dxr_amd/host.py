@@ -89,12 +89,14 @@ class Mesh:
         self.indices = np.zeros(0, np.uint32)
         self.mesh_id = None
 
-    def load(self, filename):
-        """Mesh::load (Mesh.cpp:6-37): True on success, False if the file cannot be opened."""
+    def load(self, filename, hardened=False):
+        """Mesh::load (Mesh.cpp:6-37): True on success, False if the file cannot be opened.
+        hardened=True additionally accepts polygons, v / v/vt / v//vn corners and negative indices."""
         L = _capi.lib()
         v, i = C.c_void_p(), C.c_void_p()
         nv, ni = C.c_uint32(), C.c_uint32()
-        rc = L.rr_host_mesh_load_obj(str(filename).encode(), C.byref(v), C.byref(nv), C.byref(i), C.byref(ni))
+        rc = L.rr_host_mesh_load_obj_ex(str(filename).encode(), 1 if hardened else 0, C.byref(v), C.byref(nv), C.byref(i),
+                                        C.byref(ni))
         if rc:
             return False
         verts = np.ctypeslib.as_array(C.cast(v, C.POINTER(C.c_uint8)), shape=(max(nv.value, 1) * 32,))

@@ -256,6 +256,25 @@ def test_frame_parity_on_the_symmetry_plane(gpu, name):
     assert np.array_equal(f32[..., :3].view(np.uint32), ref["rgb"].view(np.uint32))
 
 
+def test_committed_golden_frames(gpu, env_png):
+    """the committed fixtures of tests/golden/frames.npz (oracle, brute force, literal recursion)"""
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "frames.npz"))
+    cases = [("cube.obj", 64, 48, dict()), ("sphere.obj", 64, 64, dict(max_refract=1)), ("monkey.obj", 96, 54, dict(max_refract=8)),
+             ("shell.obj", 64, 48, dict()), ("ott.obj", 48, 36, dict(max_refract=8))]
+    for name, w, h, kw in cases:
+        m = load(name)
+        gpu_scene(gpu, [m], env_png)
+        gpu.set_tile_partition(0, 1)
+        gpu.set_camera(rr.camera_orbit(0.01))
+        gpu.dispatch_rays(w, h, rr.default_params(flags=rr.DISPATCH_FLOAT_OUTPUT | rr.DISPATCH_COLLECT_STATS, **kw))
+        rgba, f32 = gpu.read_frame(want_float=True)
+        st = gpu.stats()
+        key = name.split(".")[0]
+        assert [st.rays, st.hits, st.misses] == gold[key + "_counts"].tolist(), name
+        assert np.abs(f32[..., :3] - gold[key + "_rgb"]).max() <= FLOAT_TOL, name
+        assert np.abs(rgba.astype(int) - gold[key + "_rgba8"].astype(int)).max() <= 1, name
+
+
 def test_frame_parity_envmap_png(gpu, env_png):
     m = load("shell.obj")
     gpu_scene(gpu, [m], env_png)

@@ -227,3 +227,29 @@ def test_image_load_failures(tmp_path):
     (tmp_path / "bad.hdr").write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_xyze\n\n-Y 2 +X 2\n" + b"\0" * 16)
     with pytest.raises(rr.RRError):
         rr.load_texture(tmp_path / "bad.hdr")
+
+
+def test_hardened_obj_loader(tmp_path):
+    """SURVEY 8f.4: quads, v//vn and bare-v corners, negative indices -- additive, default unchanged."""
+    for name in LOADER_GOLD:                                   # hardened mode reads the reference's files identically
+        a, b = rr.Mesh(), rr.Mesh()
+        assert a.load(O.asset(name)) and b.load(O.asset(name), hardened=True)
+        assert a.verts.tobytes() == b.verts.tobytes() and np.array_equal(a.indices, b.indices)
+    p = tmp_path / "q.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nvt 0.5 0.25\n"
+                 "f 1//1 2//1 3//1 4//1\n"          # quad, no uv
+                 "f -4 -3 -2\n"                      # negative indices, no uv, no normal
+                 "f 1/1 2/1 3/1\n")                  # uv but no normal
+    strict = rr.Mesh()
+    assert strict.load(str(p)) and len(strict.verts) == 0      # the reference's sscanf pattern matches none of these
+    m = rr.Mesh()
+    assert m.load(str(p), hardened=True)
+    assert len(m.verts) == 12 and np.array_equal(m.indices, np.arange(12, dtype=np.uint32))
+    P = m.verts["position"]
+    assert np.array_equal(P[:6], [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 0, 0), (1, 1, 0), (0, 1, 0)])   # fan
+    assert np.array_equal(P[6:9], [(0, 0, 0), (1, 0, 0), (1, 1, 0)])
+    assert np.all(m.verts["norm"][:6] == (0, 0, 1)) and np.all(m.verts["uv"][:6] == 0)
+    assert np.allclose(m.verts["norm"][6:12], (0, 0, 1))       # flat winding normal where vn is absent
+    assert np.all(m.verts["uv"][9:12] == (0.5, 0.25))
+    p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 9\n")
+    assert rr.Mesh().load(str(p), hardened=True) is False      # out of range

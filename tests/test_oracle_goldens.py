@@ -1,5 +1,7 @@
 """Pins the CPU oracle against every golden the survey recorded for the reference (SURVEY.md
 Appendix A.1, B, C) and against closed-form scenes.  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -237,3 +239,18 @@ def test_bvh_equals_brute_force_on_the_symmetry_plane(name, env_png):
     b = s.render(M, cam, 120, 67, O.default_params(use_bvh=1, max_refract=8), want_rays=True)
     assert np.array_equal(a["rays"], b["rays"])
     assert np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
+
+
+def test_committed_golden_frames_are_reproduced():
+    """tests/golden/frames.npz (made by tests/golden/make_goldens.py) pins the oracle against drift"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_goldens", os.path.join(os.path.dirname(__file__), "golden", "make_goldens.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "frames.npz"))
+    for name, w, h, kw in mg.CASES:
+        rgba, rgb, cnt = mg.render(name, w, h, kw)
+        key = name.split(".")[0]
+        assert np.array_equal(rgba, gold[key + "_rgba8"]), name
+        assert np.array_equal(rgb.view(np.uint32), gold[key + "_rgb"].view(np.uint32)), name
+        assert np.array_equal(cnt, gold[key + "_counts"]), name
