@@ -85,7 +85,7 @@ def cpu_baseline(mesh, env, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=384)
+    ap.add_argument("--steps", type=int, default=1536)
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--depth1", action="store_true", help="also time the reference's shape, one DispatchRays per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
