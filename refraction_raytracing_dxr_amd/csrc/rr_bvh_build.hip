@@ -90,7 +90,11 @@ __global__ __launch_bounds__(256) void k_inst_boxes(const InstDev* __restrict__ 
             lo[0] = fminf(lo[0], wx); lo[1] = fminf(lo[1], wy); lo[2] = fminf(lo[2], wz);
             hi[0] = fmaxf(hi[0], wx); hi[1] = fmaxf(hi[1], wy); hi[2] = fmaxf(hi[2], wz);
         }
-        for (int k = 0; k < 3; ++k) { b.prim_box[(size_t)p * 6 + k] = lo[k]; b.prim_box[(size_t)p * 6 + 3 + k] = hi[k]; }
+        // the corners were rounded by the transform: grow the box a little so it still contains the instance
+        for (int k = 0; k < 3; ++k) {
+            lo[k] -= fmaf(fabsf(lo[k]), 1e-5f, 1e-7f); hi[k] += fmaf(fabsf(hi[k]), 1e-5f, 1e-7f);
+            b.prim_box[(size_t)p * 6 + k] = lo[k]; b.prim_box[(size_t)p * 6 + 3 + k] = hi[k];
+        }
     }
     reduce_scene_box(lo, hi, valid, b.scene_box);
 }
@@ -282,7 +286,8 @@ __global__ __launch_bounds__(256) void k_pack_nodes(BuildBuffers b)
             nd.lox[0] = b.node_box[0]; nd.loy[0] = b.node_box[1]; nd.loz[0] = b.node_box[2];
             nd.hix[0] = b.node_box[3]; nd.hiy[0] = b.node_box[4]; nd.hiz[0] = b.node_box[5];
             nd.lox[1] = nd.loy[1] = nd.loz[1] = inf; nd.hix[1] = nd.hiy[1] = nd.hiz[1] = -inf;
-            nd.c[0] = ~0; nd.c[1] = ~0; nd.pad[0] = 0; nd.pad[1] = 0;
+            const int leaf0 = b.leaf_ref_prim ? ~(int)b.leaf_base : ~0;
+            nd.c[0] = leaf0; nd.c[1] = leaf0; nd.pad[0] = 0; nd.pad[1] = 0;
             b.nodes[0] = nd;
         }
         return;
@@ -291,8 +296,8 @@ __global__ __launch_bounds__(256) void k_pack_nodes(BuildBuffers b)
     int l = b.child[2 * i], r = b.child[2 * i + 1];
     const size_t il = (size_t)(l >= 0 ? l : (n - 1) + ~l), ir = (size_t)(r >= 0 ? r : (n - 1) + ~r);
     if (b.leaf_ref_prim) {
-        if (l < 0) l = ~(int)(b.keys[~l] & 0xffffffffull);
-        if (r < 0) r = ~(int)(b.keys[~r] & 0xffffffffull);
+        if (l < 0) l = ~(int)(b.leaf_base + (uint32_t)(b.keys[~l] & 0xffffffffull));
+        if (r < 0) r = ~(int)(b.leaf_base + (uint32_t)(b.keys[~r] & 0xffffffffull));
     }
     BvhNode nd;
     const float* bl = b.node_box + il * 6;
@@ -323,6 +328,16 @@ __global__ __launch_bounds__(256) void k_pack_tris(const float* __restrict__ ver
     m.pad0 = 0; m.pad1 = 0; m.pad2 = 0;
     tris[i] = t;
     nrms[i] = m;
+}
+
+__global__ __launch_bounds__(256) void k_rebase_nodes(BvhNode* __restrict__ dst, const BvhNode* __restrict__ src, uint32_t n,
+                                                      uint32_t node_off, uint32_t tri_off)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    BvhNode nd = src[i];
+    for (int k = 0; k < 2; ++k) nd.c[k] = nd.c[k] >= 0 ? nd.c[k] + (int)node_off : ~(int)((uint32_t)~nd.c[k] + tri_off);
+    dst[i] = nd;
 }
 
 __global__ __launch_bounds__(256) void k_env_pad(const float* __restrict__ rgb, float4* __restrict__ out, uint32_t n)
@@ -373,6 +388,13 @@ hipError_t launch_pack_tris(const void* verts, const uint32_t* idx, const BuildB
                             hipStream_t s)
 {
     hipLaunchKernelGGL(k_pack_tris, dim3(cdiv(b.n, 256u)), dim3(256), 0, s, (const float*)verts, idx, b, tris, nrms);
+    return hipGetLastError();
+}
+
+hipError_t launch_rebase_nodes(BvhNode* dst, const BvhNode* src, uint32_t n_nodes, uint32_t node_off, uint32_t tri_off, hipStream_t s)
+{
+    if (n_nodes == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rebase_nodes, dim3(cdiv(n_nodes, 256u)), dim3(256), 0, s, dst, src, n_nodes, node_off, tri_off);
     return hipGetLastError();
 }
 

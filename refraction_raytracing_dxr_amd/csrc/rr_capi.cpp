@@ -67,7 +67,10 @@ struct rr_context {
     // TLAS
     std::vector<rr_instance_desc> inst_host;
     InstDev* d_insts = nullptr;
-    BvhNode* d_tlas = nullptr;
+    BvhNode* d_pool_nodes = nullptr;   // flattened scene: TLAS nodes, then every BLAS in use
+    TriRec*  d_pool_tris = nullptr;
+    NrmRec*  d_pool_nrms = nullptr;
+    uint32_t n_pool_tris = 0;
     uint32_t n_insts = 0, tlas_depth = 0;
     bool tlas_built = false;
     bool single_identity = false;
@@ -200,9 +203,10 @@ void fill_scene(const rr_context* ctx, SceneDev& sc)
         sc.blas0.nodes = m0->nodes; sc.blas0.tris = m0->tris; sc.blas0.nrms = m0->nrms;
         sc.blas0.n_tris = m0->n_tris; sc.blas0.depth = m0->depth; sc.blas0.scale = m0->scale;
     }
-    sc.tlas_nodes = ctx->d_tlas;
+    sc.pool_nodes = ctx->d_pool_nodes; sc.pool_tris = ctx->d_pool_tris; sc.pool_nrms = ctx->d_pool_nrms;
     sc.insts = ctx->d_insts;
     sc.n_insts = ctx->n_insts;
+    sc.n_pool_tris = ctx->n_pool_tris;
     sc.single_identity = ctx->single_identity ? 1u : 0u;
     sc.scale = ctx->scene_scale;
     sc.env = ctx->d_env;
@@ -272,7 +276,7 @@ int rr_destroy(rr_context* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (MeshRes& m : ctx->meshes) { dfree(m.d_verts); dfree(m.d_idx); dfree(m.nodes); dfree(m.tris); dfree(m.nrms); }
-    dfree(ctx->d_env); dfree(ctx->d_insts); dfree(ctx->d_tlas); dfree(ctx->d_rgba8); dfree(ctx->d_f32);
+    dfree(ctx->d_env); dfree(ctx->d_insts); dfree(ctx->d_pool_nodes); dfree(ctx->d_pool_tris); dfree(ctx->d_pool_nrms); dfree(ctx->d_rgba8); dfree(ctx->d_f32);
     dfree(ctx->d_assembled); dfree(ctx->d_cnt); dfree(ctx->d_rays); dfree(ctx->d_hits); dfree(ctx->d_cams);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
@@ -389,6 +393,19 @@ int rr_build_tlas(rr_context* ctx, const rr_instance_desc* instances, uint32_t n
         if (!ctx->meshes[(size_t)instances[i].blas].built) return fail(ctx, RR_ERR_STATE, "rr_build_tlas: BLAS not built");
     }
     static const float ident[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
+    // pool layout: nodes [0, n_tlas) TLAS, then each distinct BLAS; triangles / normals concatenated
+    const uint32_t n_tlas = n > 1 ? n - 1 : 1;
+    std::vector<uint32_t> node_off(ctx->meshes.size(), 0xffffffffu), tri_off(ctx->meshes.size(), 0);
+    uint32_t n_pool_nodes = n_tlas, n_pool_tris = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const size_t mi = (size_t)instances[i].blas;
+        if (node_off[mi] != 0xffffffffu) continue;
+        const MeshRes& m = ctx->meshes[mi];
+        node_off[mi] = n_pool_nodes; tri_off[mi] = n_pool_tris;
+        n_pool_nodes += m.n_tris > 1 ? m.n_tris - 1 : 1;
+        n_pool_tris += m.n_tris;
+    }
+    if ((uint64_t)n_pool_tris + n >= 0x7fffffffull) return fail(ctx, RR_ERR_UNSUPPORTED, "rr_build_tlas: scene too large for 31-bit leaf refs");
     std::vector<InstDev> host(n);
     float scene_scale = 0.0f;
     std::vector<float> xb((size_t)n * 18);
@@ -404,8 +421,8 @@ int rr_build_tlas(rr_context* ctx, const rr_instance_desc* instances, uint32_t n
             for (int k = 0; k < 12; ++k)
                 if (!std::isfinite(o.inv[k])) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_build_tlas: singular instance transform");
         }
-        o.blas.nodes = m.nodes; o.blas.tris = m.tris; o.blas.nrms = m.nrms; o.blas.n_tris = m.n_tris; o.blas.depth = m.depth;
-        o.blas.scale = m.scale;
+        o.root = node_off[(size_t)d.blas];
+        o.scale = m.scale;
         for (int c = 0; c < 8; ++c) {       // world-space extent of the instance (for the TLAS box padding)
             const float x = (c & 1) ? m.bounds[3] : m.bounds[0], y = (c & 2) ? m.bounds[4] : m.bounds[1], z = (c & 4) ? m.bounds[5] : m.bounds[2];
             for (int r = 0; r < 3; ++r)
@@ -417,9 +434,11 @@ int rr_build_tlas(rr_context* ctx, const rr_instance_desc* instances, uint32_t n
         memcpy(&xb[(size_t)n * 12 + (size_t)i * 6], m.bounds, 24);
     }
     ctx->tlas_built = false;
-    dfree(ctx->d_insts); dfree(ctx->d_tlas);
+    dfree(ctx->d_insts); dfree(ctx->d_pool_nodes); dfree(ctx->d_pool_tris); dfree(ctx->d_pool_nrms);
     RR_HIP(hipMalloc(&ctx->d_insts, (size_t)n * sizeof(InstDev)));
-    RR_HIP(hipMalloc(&ctx->d_tlas, (size_t)(n > 1 ? n - 1 : 1) * sizeof(BvhNode)));
+    RR_HIP(hipMalloc(&ctx->d_pool_nodes, (size_t)n_pool_nodes * sizeof(BvhNode)));
+    RR_HIP(hipMalloc(&ctx->d_pool_tris, (size_t)n_pool_tris * sizeof(TriRec)));
+    RR_HIP(hipMalloc(&ctx->d_pool_nrms, (size_t)n_pool_tris * sizeof(NrmRec)));
     float* d_xb = nullptr;
     RR_HIP(hipMalloc(&d_xb, xb.size() * 4));
     BuildScratch s;
@@ -427,18 +446,27 @@ int rr_build_tlas(rr_context* ctx, const rr_instance_desc* instances, uint32_t n
     hipError_t e = hipSuccess;
     uint32_t depth = 0;
     if (rc == RR_OK) {
-        s.b.nodes = ctx->d_tlas;
+        s.b.nodes = ctx->d_pool_nodes;
         s.b.leaf_ref_prim = 1;
+        s.b.leaf_base = n_pool_tris;                  // an instance leaf is ~(n_pool_tris + instance index)
         e = hipMemcpyAsync(ctx->d_insts, host.data(), (size_t)n * sizeof(InstDev), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(d_xb, xb.data(), xb.size() * 4, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = launch_inst_setup(ctx->d_insts, d_xb, n, s.b, ctx->stream);
         if (e == hipSuccess) e = launch_lbvh(s.b, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(&depth, s.b.depth, 4, hipMemcpyDeviceToHost, ctx->stream);
+        for (size_t mi = 0; mi < ctx->meshes.size() && e == hipSuccess; ++mi) {
+            if (node_off[mi] == 0xffffffffu) continue;
+            const MeshRes& m = ctx->meshes[mi];
+            e = launch_rebase_nodes(ctx->d_pool_nodes + node_off[mi], m.nodes, m.n_tris > 1 ? m.n_tris - 1 : 1, node_off[mi], tri_off[mi], ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_pool_tris + tri_off[mi], m.tris, (size_t)m.n_tris * sizeof(TriRec), hipMemcpyDeviceToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_pool_nrms + tri_off[mi], m.nrms, (size_t)m.n_tris * sizeof(NrmRec), hipMemcpyDeviceToDevice, ctx->stream);
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     }
     (void)hipFree(d_xb);
     if (rc != RR_OK) return rc;
     if (e != hipSuccess) return fail(ctx, RR_ERR_DEVICE, "TLAS build", e);
+    ctx->n_pool_tris = n_pool_tris;
     ctx->inst_host.assign(instances, instances + n);
     ctx->n_insts = n;
     ctx->scene_scale = scene_scale;

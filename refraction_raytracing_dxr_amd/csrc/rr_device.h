@@ -284,6 +284,9 @@ __device__ __forceinline__ f3 xform_dir(const float* m, f3 p)
 }
 
 // TraceRay(Scene, flags, 0xff, 0,0,0, ray, payload): closest hit over TLAS -> BLAS.
+// TLAS = false: the reference's scene, one BLAS.  TLAS = true: one loop over the flattened node pool;
+// reaching an instance leaf swaps the lane's ray for its object-space image (t is preserved: the
+// direction is not renormalised) and remembers the stack level, exhausting that level swaps it back.
 template <int STACK, bool STATS, bool TLAS>
 __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, float tmin, float tmax, uint32_t flags,
                                             HitRec& best, uint32_t* stk, uint32_t* err, TravCounters& cnt,
@@ -295,41 +298,51 @@ __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, floa
         trace_blas<STACK, STATS>(sc.blas0, O, D, tmin, flags, 0u, best, Stack32{ stk }, 0, err, cnt, dg);
         return;
     }
-    // two-level: the TLAS is a BVH2 of the same node type whose leaves are instance indices
-    const BoxRay br = box_ray(O, D, sc.scale);
-    const float4* __restrict__ nodes = reinterpret_cast<const float4*>(sc.tlas_nodes);
-    int sp = 0;
-    int node = 0;
+    const float4* __restrict__ nodes = reinterpret_cast<const float4*>(sc.pool_nodes);
+    const Stack32 st{ stk };
+    constexpr uint32_t NO_INST = 0xffffffffu;
+    BoxRay br = box_ray(O, D, sc.scale);
+    f3 Oc = O, Dc = D;                      // the ray in the space of the level being walked
+    uint32_t cull = flags, cur = NO_INST;
+    int sp = 0, floor = 0, node = 0;        // floor: stack level at which the current instance was entered
+    uint32_t e = 0;
     for (;;) {
         while (node >= 0) {
             const float4* q = nodes + (uint32_t)node * 4u;
             const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             if (STATS) cnt.nodes++;
-            // instance boxes are boxes of transformed corners (rounded): grow them by a few ulps
-            const float g = 1e-5f;
-            const float4 g0 = make_float4(q0.x - g * fabsf(q0.x), q0.y - g * fabsf(q0.y), q0.z - g * fabsf(q0.z), q0.w - g * fabsf(q0.w));
-            const float4 g1 = make_float4(q1.x - g * fabsf(q1.x), q1.y - g * fabsf(q1.y), q1.z + g * fabsf(q1.z), q1.w + g * fabsf(q1.w));
-            const float4 g2 = make_float4(q2.x + g * fabsf(q2.x), q2.y + g * fabsf(q2.y), q2.z + g * fabsf(q2.z), q2.w + g * fabsf(q2.w));
-            node = node_step<true>(br, g0, g1, g2, q3, tmin, best.t, Stack32{ stk }, sp, 0, STACK, *err);
+            node = node_step<true>(br, q0, q1, q2, q3, tmin, best.t, st, sp, floor, STACK, e);
         }
-        if (node == TRAV_DONE) break;
-        {
-            const uint32_t ii = (uint32_t)~node;
+        if (node == TRAV_DONE) {
+            if (cur == NO_INST) break;
+            cur = NO_INST; Oc = O; Dc = D; cull = flags; floor = 0;          // leave the instance
+            br = box_ray(O, D, sc.scale);
+            if (sp > 0) { --sp; node = st.pop(sp); continue; }
+            break;
+        }
+        const uint32_t L = (uint32_t)~node;
+        if (L < sc.n_pool_tris) {
+            if (STATS) cnt.tris++;
+            tri_test(sc.pool_tris, L, Oc, Dc, tmin, cull, cur, best);
+            if (sp > floor) { --sp; node = st.pop(sp); } else node = TRAV_DONE;
+        } else {
+            const uint32_t ii = L - sc.n_pool_tris;
             const InstDev& in = sc.insts[ii];
-            if (in.mask & 0xffu) {                       // InstanceInclusionMask 0xff
+            if (in.mask & 0xffu) {                                            // InstanceInclusionMask 0xff
                 uint32_t f = flags;
-                if (in.flags & 0x1u) f &= ~(CULL_BACK | CULL_FRONT);
-                else if (in.flags & 0x2u) {
+                if (in.flags & 0x1u) f &= ~(CULL_BACK | CULL_FRONT);          // TRIANGLE_CULL_DISABLE
+                else if (in.flags & 0x2u) {                                    // TRIANGLE_FRONT_COUNTERCLOCKWISE
                     if (f & CULL_BACK) f = (f & ~CULL_BACK) | CULL_FRONT;
                     else if (f & CULL_FRONT) f = (f & ~CULL_FRONT) | CULL_BACK;
                 }
-                f3 Oo = O, Do = D;
-                if (!in.identity) { Oo = xform_point(in.inv, O); Do = xform_dir(in.inv, D); }
-                trace_blas<STACK, STATS>(in.blas, Oo, Do, tmin, f, ii, best, Stack32{ stk }, sp, err, cnt);
-            }
+                cull = f; cur = ii; floor = sp;
+                if (!in.identity) { Oc = xform_point(in.inv, O); Dc = xform_dir(in.inv, D); }
+                br = box_ray(Oc, Dc, in.scale);
+                node = (int)in.root;
+            } else if (sp > 0) { --sp; node = st.pop(sp); } else node = TRAV_DONE;
         }
-        if (sp > 0) { --sp; node = (int)stk[sp * 64]; } else node = TRAV_DONE;
     }
+    if (e) *err = 1u;
 }
 
 // ---- Miss: RayTracing.hlsl:127-137 -------------------------------------------------------------
@@ -382,8 +395,7 @@ __device__ __forceinline__ f3 camera_ray_dir(const float* M, uint32_t x, uint32_
 template <bool TLAS>
 __device__ __forceinline__ f3 shading_normal(const SceneDev& sc, const HitRec& h)
 {
-    const BlasDev& bl = !TLAS ? sc.blas0 : sc.insts[h.inst].blas;
-    const float4* q = reinterpret_cast<const float4*>(bl.nrms + h.leaf);
+    const float4* q = reinterpret_cast<const float4*>((!TLAS ? sc.blas0.nrms : sc.pool_nrms) + h.leaf);
     float4 a = q[0], b = q[1], c = q[2];
     float u = h.U / h.ad, v = h.V / h.ad;
     f3 A = mk3(a.x, a.y, a.z);

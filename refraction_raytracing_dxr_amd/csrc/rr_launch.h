@@ -35,7 +35,8 @@ struct BuildBuffers {
     uint32_t* scene_box;            // 6 ordered-uint encodings of the scene bounds
     uint32_t* depth;                // 1
     BvhNode* nodes;                 // out: max(n-1,1)
-    uint32_t leaf_ref_prim;         // 0: leaf ref = ~sorted position (BLAS); 1: ~primitive index (TLAS)
+    uint32_t leaf_ref_prim;         // 0: leaf ref = ~sorted position (BLAS); 1: ~(leaf_base + primitive index) (TLAS)
+    uint32_t leaf_base;
 };
 
 hipError_t launch_tri_setup(const void* verts, const uint32_t* idx, uint32_t n_tris, const BuildBuffers& b, hipStream_t s);
@@ -44,6 +45,8 @@ hipError_t launch_lbvh(const BuildBuffers& b, hipStream_t s);
 hipError_t launch_pack_tris(const void* verts, const uint32_t* idx, const BuildBuffers& b, TriRec* tris, NrmRec* nrms,
                             hipStream_t s);
 hipError_t launch_inst_setup(const InstDev* insts, const float* blas_bounds, uint32_t n, const BuildBuffers& b, hipStream_t s);
+// copy a BLAS into the scene pool: internal refs += node_off, leaf refs ~l -> ~(l + tri_off)
+hipError_t launch_rebase_nodes(BvhNode* dst, const BvhNode* src, uint32_t n_nodes, uint32_t node_off, uint32_t tri_off, hipStream_t s);
 hipError_t launch_env_pad(const float* rgb, float4* out, uint32_t n_texels, hipStream_t s);
 
 } // namespace rr

@@ -19,6 +19,9 @@
 #ifndef RR_FUSED_WAVES_PER_SIMD
 #define RR_FUSED_WAVES_PER_SIMD 5
 #endif
+#ifndef RR_TLAS_WAVES_PER_SIMD
+#define RR_TLAS_WAVES_PER_SIMD 4
+#endif
 
 namespace rr {
 
@@ -47,7 +50,7 @@ __device__ __forceinline__ void block_to_tile(uint32_t b, uint32_t& tile_local, 
 }
 
 template <int STACK, int PEND, bool STATS, bool TLAS, bool DIAG = false>
-__global__ __launch_bounds__(256, RR_FUSED_WAVES_PER_SIMD) void k_render_fused(SceneDev sc, DispatchDev a)
+__global__ __launch_bounds__(256, TLAS ? RR_TLAS_WAVES_PER_SIMD : RR_FUSED_WAVES_PER_SIMD) void k_render_fused(SceneDev sc, DispatchDev a)
 {
     __shared__ uint32_t diag_trips[12];    // per wave: internal trips, leaf trips, shading passes
     const unsigned long long diag_t0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;

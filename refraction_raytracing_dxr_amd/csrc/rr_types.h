@@ -50,21 +50,28 @@ struct BlasDev {
 // instance record for two-level traversal (derived from the 64-byte rr_instance_desc)
 struct alignas(16) InstDev {
     float inv[12];            // world -> object 3x4
-    BlasDev blas;
+    uint32_t root;            // root node of this instance's BLAS inside the scene pool
     uint32_t flags;           // RR_INSTANCE_FLAG_*
     uint32_t mask;
     uint32_t identity;
-    uint32_t pad;
+    float    scale;           // largest |coordinate| of the BLAS bounds (box-test padding in object space)
+    uint32_t pad[3];
 };
 
+// Scenes beyond the reference's single identity instance are FLATTENED at rr_build_tlas: the TLAS nodes
+// and the nodes of every BLAS in use live in one node pool (child refs rebased), triangles and normals
+// in one pool each.  A leaf ref ~L is a triangle for L < n_pool_tris and instance L - n_pool_tris
+// otherwise, so one traversal loop walks both levels.
 struct SceneDev {
     BlasDev  blas0;           // used directly when the scene is one identity instance (the reference's case)
-    const BvhNode* tlas_nodes;
+    const BvhNode* pool_nodes;    // [0, n_insts-1): TLAS, then the BLASes
+    const TriRec*  pool_tris;
+    const NrmRec*  pool_nrms;
     const InstDev* insts;
     uint32_t n_insts;
+    uint32_t n_pool_tris;
     uint32_t single_identity; // 1: skip the top level entirely
     float scale;              // largest |coordinate| of the world-space scene bounds
-    uint32_t pad0;
     const float4* env;        // w*h float4
     int32_t env_w, env_h;
 };
