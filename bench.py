@@ -21,7 +21,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np
 
@@ -60,7 +59,8 @@ def host_cores():
 def cpu_baseline(mesh, env, budget_s=15.0):
     """The CPU oracle (oracle/, C, fp32, median-split BVH, one pthread per host core) timed on a
     bounded sample of the same workload: whole 1920x1080 frames of the same orbit."""
-    import oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O                      # the checker: only this leg of bench.py touches oracle/
     import refraction_raytracing_dxr_amd as rr
     cores = host_cores()
     s = O.Scene()
@@ -95,8 +95,7 @@ def main():
 
     import torch
     import refraction_raytracing_dxr_amd as rr
-    import oracle as O                      # only for asset paths and the cpu_baseline leg
-    from conftest import procedural_env
+    from refraction_raytracing_dxr_amd.synth import asset, procedural_env
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -120,7 +119,7 @@ def main():
             dist.init_process_group(backend=backend)
 
     mesh = rr.Mesh()
-    assert mesh.load(O.asset("monkey.obj"))
+    assert mesh.load(asset("monkey.obj"))
     env = procedural_env(ENV_W, ENV_H, seed=0)
     r = rr.Renderer(local_rank)
     r.set_stream(torch.cuda.current_stream().cuda_stream)       # so torch.cuda.synchronize() covers the kernels

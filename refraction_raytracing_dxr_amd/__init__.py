@@ -8,7 +8,7 @@ from ._capi import (DISPATCH_COLLECT_STATS, DISPATCH_FLOAT_OUTPUT, DISPATCH_KEEP
                     lib_path)
 from .host import (ASPECT, FOV_Y, Mesh, RefractionDemo, Renderer, camera_orbit, default_params, load_texture,
                    make_instances, scene_constants, write_hdr)
-from . import dist
+from . import dist, synth
 
 __all__ = ["Mesh", "RefractionDemo", "Renderer", "camera_orbit", "default_params", "load_texture", "make_instances",
            "scene_constants", "write_hdr", "dist", "lib", "lib_path", "RRError"]
