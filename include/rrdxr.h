@@ -138,7 +138,13 @@ int  rr_upload_envmap(rr_context* ctx, const float* rgb, int32_t w, int32_t h);
 
 /* ---- acceleration structures: RefractionDemo.cpp:272-361 ----------------------------------- */
 /* BuildRaytracingAccelerationStructure (bottom level), :277-322 */
-int  rr_build_blas(rr_context* ctx, uint32_t mesh_id);
+int  rr_build_blas(rr_context* ctx, uint32_t mesh_id);       /* = PREFER_FAST_TRACE, the flag the reference passes (:286) */
+/* D3D12_RAYTRACING_ACCELERATION_STRUCTURE_BUILD_FLAG_PREFER_FAST_TRACE / _FAST_BUILD (same bit values):
+ * FAST_TRACE builds a clustered (PLOC) hierarchy for meshes up to 32768 triangles, the Morton LBVH above
+ * that; FAST_BUILD always builds the LBVH. */
+#define RR_BUILD_PREFER_FAST_TRACE 0x4u
+#define RR_BUILD_PREFER_FAST_BUILD 0x8u
+int  rr_build_blas_ex(rr_context* ctx, uint32_t mesh_id, uint32_t flags);
 /* BuildRaytracingAccelerationStructure (top level), :324-356.  n == 0 is invalid; the
  * reference's scene is one identity instance with mask 1 and flags 0. */
 int  rr_build_tlas(rr_context* ctx, const rr_instance_desc* instances, uint32_t n);

@@ -15,6 +15,8 @@ DISPATCH_FLOAT_OUTPUT = 0x1
 DISPATCH_COLLECT_STATS = 0x2
 DISPATCH_TIME_KERNEL = 0x4
 DISPATCH_KEEP_COUNTERS = 0x8
+BUILD_PREFER_FAST_TRACE = 0x4
+BUILD_PREFER_FAST_BUILD = 0x8
 RAY_FLAG_CULL_BACK = 0x10
 RAY_FLAG_CULL_FRONT = 0x20
 INSTANCE_FLAG_CULL_DISABLE = 0x1
@@ -66,6 +68,7 @@ SYMBOLS = {
     "rr_upload_mesh": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
     "rr_upload_envmap": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     "rr_build_blas": (C.c_int, [_P, C.c_uint32]),
+    "rr_build_blas_ex": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "rr_build_tlas": (C.c_int, [_P, _P, C.c_uint32]),
     "rr_set_camera": (C.c_int, [_P, C.POINTER(SceneConstants)]),
     "rr_set_tile_partition": (C.c_int, [_P, C.c_uint32, C.c_uint32]),

@@ -230,6 +230,115 @@ __global__ __launch_bounds__(256) void k_karras(BuildBuffers b)
     if (i == 0) b.parent[0] = -1;
 }
 
+// ---- PLOC (Meister & Bittner 2018): agglomerative clustering in Morton order -------------------
+// The D3D12 build flag the reference passes is PREFER_FAST_TRACE (RefractionDemo.cpp:286): for meshes of up
+// to PLOC_MAX_PRIMS triangles the Karras radix tree is replaced by this bottom-up builder, which merges
+// mutually-nearest neighbours (surface area of the merged box, search radius PLOC_RADIUS in the Morton
+// order) until one cluster is left.  One workgroup; every step is deterministic (ids come from scans,
+// not atomics).  Output conventions are those of k_karras + k_refit: child[], parent[], node_box[].
+#ifndef RR_PLOC_RADIUS
+#define RR_PLOC_RADIUS 16
+#endif
+constexpr int PLOC_RADIUS = RR_PLOC_RADIUS;
+
+__device__ __forceinline__ float merged_area(const float* a, const float* c)
+{
+    const float dx = fmaxf(a[3], c[3]) - fminf(a[0], c[0]);
+    const float dy = fmaxf(a[4], c[4]) - fminf(a[1], c[1]);
+    const float dz = fmaxf(a[5], c[5]) - fminf(a[2], c[2]);
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// exclusive scan of one packed u32 per thread over the 1024-thread workgroup; returns the total
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t& excl, uint32_t* lds /* 16 words */)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= (uint32_t)o) inc += t; }
+    if (lane == 63u) lds[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (uint32_t w = 0; w < 16u; ++w) { const uint32_t t = lds[w]; if (w < wave) base += t; total += t; }
+    __syncthreads();
+    excl = base + inc - v;
+    return total;
+}
+
+__global__ __launch_bounds__(1024) void k_ploc(BuildBuffers b)
+{
+    __shared__ uint32_t scan_lds[16];
+    const int n = (int)b.n;
+    const int tid = (int)threadIdx.x;
+    uint32_t* A = b.ploc;
+    uint32_t* B = b.ploc + b.n;
+    int* NN = reinterpret_cast<int*>(b.visit);
+    for (int i = tid; i < n; i += 1024) {
+        const uint32_t prim = (uint32_t)(b.keys[i] & 0xffffffffull);
+        for (int k = 0; k < 6; ++k) b.node_box[(size_t)(n - 1 + i) * 6 + k] = b.prim_box[(size_t)prim * 6 + k];
+        A[i] = (uint32_t)(n - 1 + i);
+    }
+    __syncthreads();
+    int m = n;
+    int next_id = n - 2;                              // internal ids are handed out downwards: the last merge is node 0
+    while (m > 1) {
+        // 1. nearest neighbour of every cluster within the radius
+        for (int i = tid; i < m; i += 1024) {
+            const float* bu = b.node_box + (size_t)A[i] * 6;
+            float best = __builtin_huge_valf();
+            int bj = -1;
+            const int j0 = i - PLOC_RADIUS < 0 ? 0 : i - PLOC_RADIUS, j1 = i + PLOC_RADIUS > m - 1 ? m - 1 : i + PLOC_RADIUS;
+            for (int j = j0; j <= j1; ++j) {
+                if (j == i) continue;
+                const float a = merged_area(bu, b.node_box + (size_t)A[j] * 6);
+                if (a < best) { best = a; bj = j; }
+            }
+            NN[i] = bj;
+        }
+        __syncthreads();
+        // 2. mutual pairs merge (the lower position keeps the new cluster), everything else survives as is
+        const int chunk = (m + 1023) / 1024;
+        const int c0 = tid * chunk, c1 = c0 + chunk < m ? c0 + chunk : m;
+        uint32_t cnt = 0;                             // low 16 bits: clusters kept, high 16: merges
+        for (int i = c0; i < c1; ++i) {
+            const int j = NN[i];
+            const bool mutual = NN[j] == i;
+            if (!mutual || i < j) cnt += 1u;
+            if (mutual && i < j) cnt += 0x10000u;
+        }
+        uint32_t excl;
+        const uint32_t total = block_scan_1024(cnt, excl, scan_lds);
+        uint32_t pos = excl & 0xffffu, mrg = excl >> 16;
+        for (int i = c0; i < c1; ++i) {
+            const int j = NN[i];
+            const bool mutual = NN[j] == i;
+            if (mutual && i < j) {
+                const int id = next_id - (int)mrg;
+                const uint32_t ul = A[i], ur = A[j];
+                const float* bl = b.node_box + (size_t)ul * 6;
+                const float* br = b.node_box + (size_t)ur * 6;
+                for (int k = 0; k < 3; ++k) {
+                    b.node_box[(size_t)id * 6 + k] = fminf(bl[k], br[k]);
+                    b.node_box[(size_t)id * 6 + 3 + k] = fmaxf(bl[3 + k], br[3 + k]);
+                }
+                b.child[2 * id] = ul >= (uint32_t)(n - 1) ? ~(int)(ul - (uint32_t)(n - 1)) : (int)ul;
+                b.child[2 * id + 1] = ur >= (uint32_t)(n - 1) ? ~(int)(ur - (uint32_t)(n - 1)) : (int)ur;
+                b.parent[ul] = id;
+                b.parent[ur] = id;
+                B[pos++] = (uint32_t)id;
+                ++mrg;
+            } else if (!mutual) {
+                B[pos++] = A[i];
+            }
+        }
+        next_id -= (int)(total >> 16);
+        m = (int)(total & 0xffffu);
+        __syncthreads();
+        uint32_t* t = A; A = B; B = t;
+        __syncthreads();
+    }
+    if (tid == 0) b.parent[0] = -1;
+}
+
 // ---- bottom-up refit: the second thread to arrive at a node owns it ---------------------------
 __global__ __launch_bounds__(256) void k_refit(BuildBuffers b)
 {
@@ -379,6 +488,25 @@ hipError_t launch_lbvh(const BuildBuffers& b, hipStream_t s)
     }
     if (b.n > 1u) hipLaunchKernelGGL(k_karras, dim3(cdiv(b.n - 1u, 256u)), dim3(256), 0, s, b);
     hipLaunchKernelGGL(k_refit, dim3(cdiv(b.n, 256u)), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_depth, dim3(cdiv(b.n, 256u)), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_pack_nodes, dim3(cdiv(b.n > 1u ? b.n - 1u : 1u, 256u)), dim3(256), 0, s, b);
+    return hipGetLastError();
+}
+
+hipError_t launch_ploc(const BuildBuffers& b, hipStream_t s)
+{
+    // keys must already be sorted (launch_lbvh's first half); builds child/parent/node_box, then depth + pack
+    const uint32_t N = b.n_pad;
+    hipLaunchKernelGGL(k_morton_keys, dim3(cdiv(N, 256u)), dim3(256), 0, s, b);
+    if (N > 1u) {
+        hipLaunchKernelGGL(k_bitonic_block, dim3(N <= SORT_CH ? 1u : N / SORT_CH), dim3(1024), 0, s, b.keys, N);
+        for (uint32_t k = SORT_CH * 2u; k <= N && k != 0u; k <<= 1) {
+            for (uint32_t j = k >> 1; j >= SORT_CH; j >>= 1)
+                hipLaunchKernelGGL(k_bitonic_global, dim3(cdiv(N / 2u, 256u)), dim3(256), 0, s, b.keys, N, k, j);
+            hipLaunchKernelGGL(k_bitonic_tail, dim3(N / SORT_CH), dim3(1024), 0, s, b.keys, N, k);
+        }
+    }
+    hipLaunchKernelGGL(k_ploc, dim3(1), dim3(1024), 0, s, b);
     hipLaunchKernelGGL(k_depth, dim3(cdiv(b.n, 256u)), dim3(256), 0, s, b);
     hipLaunchKernelGGL(k_pack_nodes, dim3(cdiv(b.n > 1u ? b.n - 1u : 1u, 256u)), dim3(256), 0, s, b);
     return hipGetLastError();

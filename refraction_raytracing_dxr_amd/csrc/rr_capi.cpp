@@ -171,7 +171,8 @@ int alloc_build(rr_context* ctx, uint32_t n, BuildScratch& s)
     size_t o_visit = o_nbox + al((size_t)(2 * (size_t)n) * 6 * 4);
     size_t o_scene = o_visit + al((size_t)n * 4);
     size_t o_depth = o_scene + al(6 * 4);
-    size_t total = o_depth + al(4);
+    size_t o_ploc = o_depth + al(4);
+    size_t total = o_ploc + al((size_t)n * 8);
     RR_HIP(hipMalloc(&s.raw, total));
     char* base = (char*)s.raw;
     s.b.n = n; s.b.n_pad = n_pad;
@@ -183,6 +184,7 @@ int alloc_build(rr_context* ctx, uint32_t n, BuildScratch& s)
     s.b.visit = (uint32_t*)(base + o_visit);
     s.b.scene_box = (uint32_t*)(base + o_scene);
     s.b.depth = (uint32_t*)(base + o_depth);
+    s.b.ploc = (uint32_t*)(base + o_ploc);
     return RR_OK;
 }
 
@@ -353,7 +355,9 @@ int rr_upload_envmap(rr_context* ctx, const float* rgb, int32_t w, int32_t h)
     return RR_OK;
 }
 
-int rr_build_blas(rr_context* ctx, uint32_t mesh_id)
+int rr_build_blas(rr_context* ctx, uint32_t mesh_id) { return rr_build_blas_ex(ctx, mesh_id, RR_BUILD_PREFER_FAST_TRACE); }
+
+int rr_build_blas_ex(rr_context* ctx, uint32_t mesh_id, uint32_t flags)
 {
     if (int r = use_device(ctx)) return r;
     if (mesh_id >= ctx->meshes.size()) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_build_blas: unknown mesh id");
@@ -368,7 +372,10 @@ int rr_build_blas(rr_context* ctx, uint32_t mesh_id)
     RR_HIP(hipMalloc(&m.nrms, (size_t)n * sizeof(NrmRec)));
     s.b.nodes = m.nodes;
     RR_HIP(launch_tri_setup(m.d_verts, m.d_idx, n, s.b, ctx->stream));
-    RR_HIP(launch_lbvh(s.b, ctx->stream));
+    if ((flags & RR_BUILD_PREFER_FAST_TRACE) && !(flags & RR_BUILD_PREFER_FAST_BUILD) && n > 1 && n <= PLOC_MAX_PRIMS)
+        RR_HIP(launch_ploc(s.b, ctx->stream));          // clustered hierarchy (fewer node visits)
+    else
+        RR_HIP(launch_lbvh(s.b, ctx->stream));          // Karras radix tree (fastest build, any size)
     RR_HIP(launch_pack_tris(m.d_verts, m.d_idx, s.b, m.tris, m.nrms, ctx->stream));
     uint32_t sb[6], depth = 0;
     RR_HIP(hipMemcpyAsync(sb, s.b.scene_box, sizeof sb, hipMemcpyDeviceToHost, ctx->stream));

@@ -34,6 +34,7 @@ struct BuildBuffers {
     uint32_t* visit;                // (n-1) arrival counters
     uint32_t* scene_box;            // 6 ordered-uint encodings of the scene bounds
     uint32_t* depth;                // 1
+    uint32_t* ploc;                 // 2*n cluster arrays of the PLOC builder
     BvhNode* nodes;                 // out: max(n-1,1)
     uint32_t leaf_ref_prim;         // 0: leaf ref = ~sorted position (BLAS); 1: ~(leaf_base + primitive index) (TLAS)
     uint32_t leaf_base;
@@ -41,6 +42,9 @@ struct BuildBuffers {
 
 hipError_t launch_tri_setup(const void* verts, const uint32_t* idx, uint32_t n_tris, const BuildBuffers& b, hipStream_t s);
 hipError_t launch_lbvh(const BuildBuffers& b, hipStream_t s);
+// PREFER_FAST_TRACE hierarchy: Morton order + parallel locally-ordered clustering (n <= PLOC_MAX_PRIMS)
+constexpr uint32_t PLOC_MAX_PRIMS = 32768;
+hipError_t launch_ploc(const BuildBuffers& b, hipStream_t s);
 // after launch_lbvh: keys[i] & 0xffffffff is the primitive of sorted leaf i
 hipError_t launch_pack_tris(const void* verts, const uint32_t* idx, const BuildBuffers& b, TriRec* tris, NrmRec* nrms,
                             hipStream_t s);

@@ -172,8 +172,10 @@ class Renderer:
         assert c == 3
         self._ck(self._L.rr_upload_envmap(self._h, rgb.ctypes.data, w, h), "rr_upload_envmap")
 
-    def build_blas(self, mesh_id):
-        self._ck(self._L.rr_build_blas(self._h, mesh_id), "rr_build_blas")
+    def build_blas(self, mesh_id, fast_build=False):
+        """BuildRaytracingAccelerationStructure (bottom level); fast_build=True forces the plain Morton LBVH"""
+        self._ck(self._L.rr_build_blas_ex(self._h, mesh_id, _capi.BUILD_PREFER_FAST_BUILD if fast_build
+                                          else _capi.BUILD_PREFER_FAST_TRACE), "rr_build_blas")
 
     def build_tlas(self, instances=None):
         inst = make_instances() if instances is None else np.ascontiguousarray(instances, INSTANCE_DTYPE)

@@ -141,6 +141,24 @@ def test_trace_rays_bit_exact_vs_brute_force(gpu, name, n):
     assert n_hit > n // 20
 
 
+def test_fast_build_and_fast_trace_hierarchies_render_the_same_frame(gpu):
+    m = load("monkey.obj")
+    env = procedural_env(128, 64, seed=31)
+    gpu.upload_envmap(env)
+    gpu.set_tile_partition(0, 1)
+    gpu.set_camera(rr.camera_orbit(0.9))
+    frames, visits = [], []
+    for fast_build in (False, True):
+        mid = gpu.upload_mesh(m.verts, m.indices)
+        gpu.build_blas(mid, fast_build=fast_build)
+        gpu.build_tlas(rr.make_instances(meshes=[mid]))
+        gpu.dispatch_rays(320, 180, rr.default_params(max_refract=8, flags=rr.DISPATCH_FLOAT_OUTPUT | rr.DISPATCH_COLLECT_STATS))
+        frames.append(gpu.read_frame(want_float=True)[1].copy())
+        visits.append(gpu.stats().node_visits)
+    assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))     # the hierarchy never changes a pixel
+    assert visits[0] < visits[1]                                                     # and FAST_TRACE does trace faster
+
+
 def test_trace_rays_empty_and_single_triangle(gpu):
     # one triangle: the degenerate LBVH (no internal node from Karras)
     v = np.zeros(3, rr.VERTEX_DTYPE)
@@ -162,11 +180,13 @@ def test_trace_rays_empty_and_single_triangle(gpu):
 
 
 # ------------------------------------------------------------------------------- BVH structure
+@pytest.mark.parametrize("fast_build", [False, True])
 @pytest.mark.parametrize("name", ["cube.obj", "monkey.obj", "ott.obj"])
-def test_lbvh_structure(gpu, name):
+def test_lbvh_structure(gpu, name, fast_build):
+    """both builders (PREFER_FAST_TRACE = clustered PLOC tree, PREFER_FAST_BUILD = Karras radix tree)"""
     m = load(name)
     mid = gpu.upload_mesh(m.verts, m.indices)
-    gpu.build_blas(mid)
+    gpu.build_blas(mid, fast_build=fast_build)
     nodes, tris = gpu.download_blas(mid)
     T = len(m.indices) // 3
     assert len(tris) == T and len(nodes) == T - 1
