@@ -56,7 +56,7 @@ def host_cores():
     return n
 
 
-def cpu_baseline(mesh, env, budget_s=15.0):
+def cpu_baseline(mesh, env, budget_s=12.0):
     """The CPU oracle (oracle/, C, fp32, median-split BVH, one pthread per host core) timed on a
     bounded sample of the same workload: whole 1920x1080 frames of the same orbit."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -75,7 +75,7 @@ def cpu_baseline(mesh, env, budget_s=15.0):
         rays += r["stats"].rays
         frames += 1
         el = time.perf_counter() - t0
-        if el > budget_s or frames >= 64:
+        if el > budget_s or frames >= 628:
             break
     return {"value": round(rays / el / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": "%d full 1920x1080 frames of the same orbit (%.1f s), CPU restatement with its own "
@@ -166,6 +166,7 @@ def main():
     # ---- roofline of the dominant kernel (k_render_fused), rank 0, single-GPU geometry ---------------------
     roofline = None
     cpu = None
+    subdiv = None
     if rank == 0:
         r.set_tile_partition(0, 1)
         n_prof = max(F, (min(K, 256) // F) * F)                              # whole launches of F slices
@@ -202,6 +203,24 @@ def main():
                     "node_visits_per_ray": round(sst.node_visits / sst.rays, 2),
                     "tri_tests_per_ray": round(sst.tri_tests / sst.rays, 2),
                     "kernel_grays_per_s": round(sst.rays / kn / (kernel_us * 1e-6) / 1e9, 3)}
+        # ---- BASELINE's "~16k tri Suzanne": monkey.obj midpoint-subdivided twice (15 472 tri), same frames ----
+        if world == 1:
+            from refraction_raytracing_dxr_amd.synth import subdivide
+            v16, i16 = subdivide(mesh.verts, 2)
+            r.load_scene(v16, i16, env)
+            n16 = max(F, (min(K, 256) // F) * F)
+            r.render_orbit(W, H, F, angle=0.01, params=params, frames_per_dispatch=F)
+            torch.cuda.synchronize()
+            t16 = time.perf_counter()
+            r.render_orbit(W, H, n16, angle=0.01, params=params, frames_per_dispatch=F)
+            torch.cuda.synchronize()
+            t16 = time.perf_counter() - t16
+            s16 = r.stats()
+            if s16.traversal_overflow:
+                raise SystemExit("traversal stack overflow on the subdivided mesh: result invalid")
+            subdiv = {"workload": "monkey.obj midpoint-subdivided x2 (%d tri), otherwise as config.workload" % (len(i16) // 3),
+                      "value": round(s16.rays / t16 / 1e6, 2), "unit": "Mrays/s", "fps": round(n16 / t16, 1), "steps": n16}
+            r.load_scene(mesh.verts, mesh.indices, env)
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(mesh, env)
 
@@ -228,6 +247,7 @@ def main():
             "device_region_ms_per_step": round(region_ms / K, 5) if region_ms is not None else None,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "monkey_16k": subdiv,
         }
         print(json.dumps(out))
     r.close()

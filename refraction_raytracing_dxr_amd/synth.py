@@ -28,3 +28,32 @@ def procedural_env(w=256, h=128, seed=0, peak=16.0):
         img += amp * m[..., None] * col
     img += rng.uniform(0, 0.02, img.shape).astype(np.float32)
     return np.clip(img, 0, peak).astype(np.float32)
+
+
+def subdivide(verts, levels=1):
+    """Midpoint subdivision of an un-indexed triangle list (the layout Mesh::load produces, Mesh.cpp:24-31):
+    every triangle becomes four, positions/uvs are edge midpoints (the surface does not move), normals are the
+    re-normalised midpoints.  monkey.obj x2 levels = 15 472 triangles, BASELINE's '~16k tri Suzanne' (SURVEY 8d).
+    Returns (verts, indices) with indices the identity, as the loader does."""
+    from ._capi import VERTEX_DTYPE
+    v = np.asarray(verts)
+    for _ in range(levels):
+        t = v.reshape(-1, 3)
+        a, b, c = t[:, 0], t[:, 1], t[:, 2]
+
+        def mid(p, q):
+            m = np.zeros(p.shape, VERTEX_DTYPE)
+            m["position"] = (p["position"] + q["position"]) * np.float32(0.5)
+            m["uv"] = (p["uv"] + q["uv"]) * np.float32(0.5)
+            n = p["norm"] + q["norm"]
+            ln = np.sqrt((n * n).sum(-1, keepdims=True, dtype=np.float32))
+            m["norm"] = np.where(ln > 0, n / np.where(ln > 0, ln, 1), p["norm"]).astype(np.float32)
+            return m
+        ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+        out = np.empty((t.shape[0], 4, 3), VERTEX_DTYPE)
+        out[:, 0, 0], out[:, 0, 1], out[:, 0, 2] = a, ab, ca
+        out[:, 1, 0], out[:, 1, 1], out[:, 1, 2] = ab, b, bc
+        out[:, 2, 0], out[:, 2, 1], out[:, 2, 2] = ca, bc, c
+        out[:, 3, 0], out[:, 3, 1], out[:, 3, 2] = ab, bc, ca
+        v = out.reshape(-1)
+    return np.ascontiguousarray(v), np.arange(v.shape[0], dtype=np.uint32)

@@ -756,3 +756,37 @@ def test_large_mesh_build_and_trace(gpu):
     ref = s.render(np.array(sc.proj_inv, np.float32), np.array(sc.camera_loc, np.float32), 640, 360,
                    O.default_params(use_bvh=1, max_refract=8, accum_mode=1), region=(280, 150, 360, 210))
     assert np.array_equal(a[150:210, 280:360], ref["rgba8"][150:210, 280:360])
+
+
+def test_subdivided_monkey_16k_frame_parity(gpu):
+    """BASELINE's '~16k tri Suzanne' = monkey.obj midpoint-subdivided twice (15 472 tri): same surface,
+    16x the hierarchy.  Float accumulator bit-equal to the oracle's path-weight mode; and since midpoint
+    subdivision moves no surface point, the image stays close to the 967-triangle one."""
+    from refraction_raytracing_dxr_amd.synth import subdivide
+    m = load("monkey.obj")
+    v16, i16 = subdivide(m.verts, 2)
+    assert len(i16) == 3 * 15472
+    env = procedural_env(128, 64, seed=5)
+    W, H = 256, 144
+    sc = rr.camera_orbit(0.4)
+    gpu.load_scene(v16, i16, env)
+    gpu.set_tile_partition(0, 1)
+    gpu.set_camera(sc)
+    gpu.dispatch_rays(W, H, rr.default_params(max_refract=8, flags=rr.DISPATCH_FLOAT_OUTPUT | rr.DISPATCH_COLLECT_STATS))
+    rgba, acc = gpu.read_frame(want_float=True)
+    st = gpu.stats()
+    assert st.traversal_overflow == 0
+    s = O.Scene()
+    s.add_mesh(v16, i16)
+    s.set_envmap(env)
+    ref = s.render(np.array(sc.proj_inv, np.float32), np.array(sc.camera_loc, np.float32), W, H,
+                   O.default_params(use_bvh=1, max_refract=8, accum_mode=1))
+    assert ref["stats"].rays == st.rays and (ref["stats"].hits, ref["stats"].misses) == (st.hits, st.misses)
+    assert np.array_equal(acc[..., :3].view(np.uint32), ref["rgb"].view(np.uint32))
+    assert np.array_equal(rgba, ref["rgba8"])
+    # the coarse mesh renders nearly the same picture (shading normals differ slightly: normalised midpoints)
+    gpu.load_scene(m.verts, m.indices, env)
+    gpu.set_camera(sc)
+    gpu.dispatch_rays(W, H, rr.default_params(max_refract=8))
+    coarse = gpu.read_frame().astype(int)
+    assert np.mean(np.abs(coarse - rgba.astype(int)) > 8) < 0.15
