@@ -198,6 +198,16 @@ int  rr_render_orbit_sharded(rr_context* ctx, uint32_t width, uint32_t height, c
                              float* angle, float angle_step, uint32_t n_frames, uint32_t frames_per_dispatch,
                              float fov_y, float aspect, float zn, float zf,
                              void* d_tiles, uint64_t frame_stride_bytes);
+/* The same, submitted to internal stream `lane` (0..3) instead of the context's stream.  The lane starts
+ * after everything submitted to the context's stream so far; the context's stream does NOT wait for the
+ * lane until rr_lane_join (rr_wait / rr_get_stats join every lane).  Keeping two lanes in flight lets the
+ * tail of one batch (a few long-running waves) overlap the head of the next, and lets the gather of batch b
+ * run while batch b+1 renders.  Lanes own their constant buffers; counters are shared (atomic). */
+int  rr_render_orbit_sharded_lane(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispatch_params* params,
+                                  float* angle, float angle_step, uint32_t n_frames, uint32_t frames_per_dispatch,
+                                  float fov_y, float aspect, float zn, float zf,
+                                  void* d_tiles, uint64_t frame_stride_bytes, uint32_t lane);
+int  rr_lane_join(rr_context* ctx, uint32_t lane);
 /* rank 0, after gathering n_frames at once: frame f of rank r lies at
  * d_gathered + r*rank_stride_bytes + f*frame_stride_bytes; writes n_frames W*H RGBA8 rasters to
  * d_frames + f*out_stride_bytes.  One launch for all frames. */

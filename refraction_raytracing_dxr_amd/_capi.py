@@ -85,6 +85,10 @@ SYMBOLS = {
     "rr_render_orbit_sharded": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(DispatchParams), C.POINTER(C.c_float),
                                           C.c_float, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float,
                                           _P, C.c_uint64]),
+    "rr_render_orbit_sharded_lane": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(DispatchParams), C.POINTER(C.c_float),
+                                               C.c_float, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float,
+                                               _P, C.c_uint64, C.c_uint32]),
+    "rr_lane_join": (C.c_int, [_P, C.c_uint32]),
     "rr_assemble_frames": (C.c_int, [_P, _P, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                      _P, C.c_uint64]),
     "rr_timing_begin": (C.c_int, [_P]),

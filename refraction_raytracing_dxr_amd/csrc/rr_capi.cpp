@@ -83,6 +83,14 @@ struct rr_context {
 
     uint32_t tile_rank = 0, tile_world = 1;
 
+    // lanes: internal streams whose launches may overlap each other (rr_render_orbit_sharded_lane)
+    static constexpr uint32_t MAX_LANES = 4;
+    hipStream_t lane_stream[MAX_LANES] = {};
+    hipEvent_t  lane_fork[MAX_LANES] = {}, lane_done[MAX_LANES] = {};
+    CamDev*     lane_cams[MAX_LANES] = {};
+    size_t      lane_cams_cap[MAX_LANES] = {};
+    bool        lane_busy[MAX_LANES] = {};
+
     // frame
     uint32_t W = 0, H = 0, frame_world = 0, frame_depth = 1;
     uint32_t* d_rgba8 = nullptr;     // world==1: W*H; else local tiles
@@ -277,6 +285,14 @@ int rr_destroy(rr_context* ctx)
     if (!ctx) return RR_ERR_INVALID_ARGUMENT;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (uint32_t l = 0; l < rr_context::MAX_LANES; ++l) {
+        if (!ctx->lane_stream[l]) continue;
+        (void)hipStreamSynchronize(ctx->lane_stream[l]);
+        (void)hipStreamDestroy(ctx->lane_stream[l]);
+        (void)hipEventDestroy(ctx->lane_fork[l]);
+        (void)hipEventDestroy(ctx->lane_done[l]);
+        dfree(ctx->lane_cams[l]);
+    }
     for (MeshRes& m : ctx->meshes) { dfree(m.d_verts); dfree(m.d_idx); dfree(m.nodes); dfree(m.tris); dfree(m.nrms); }
     dfree(ctx->d_env); dfree(ctx->d_insts); dfree(ctx->d_pool_nodes); dfree(ctx->d_pool_tris); dfree(ctx->d_pool_nrms); dfree(ctx->d_rgba8); dfree(ctx->d_f32);
     dfree(ctx->d_assembled); dfree(ctx->d_cnt); dfree(ctx->d_rays); dfree(ctx->d_hits); dfree(ctx->d_cams);
@@ -306,10 +322,35 @@ int rr_reset_stream(rr_context* ctx)
     return RR_OK;
 }
 
+namespace {
+// the context's stream waits for everything submitted to the lanes
+int join_lanes(rr_context* ctx)
+{
+    for (uint32_t l = 0; l < rr_context::MAX_LANES; ++l)
+        if (ctx->lane_busy[l]) {
+            RR_HIP(hipStreamWaitEvent(ctx->stream, ctx->lane_done[l], 0));
+            ctx->lane_busy[l] = false;
+        }
+    return RR_OK;
+}
+} // namespace
+
 int rr_wait(rr_context* ctx)
 {
     if (int r = use_device(ctx)) return r;
+    if (int r = join_lanes(ctx)) return r;
     RR_HIP(hipStreamSynchronize(ctx->stream));
+    return RR_OK;
+}
+
+int rr_lane_join(rr_context* ctx, uint32_t lane)
+{
+    if (int r = use_device(ctx)) return r;
+    if (lane >= rr_context::MAX_LANES) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_lane_join: lane out of range");
+    if (ctx->lane_busy[lane]) {
+        RR_HIP(hipStreamWaitEvent(ctx->stream, ctx->lane_done[lane], 0));
+        ctx->lane_busy[lane] = false;
+    }
     return RR_OK;
 }
 
@@ -791,6 +832,47 @@ int rr_render_orbit_sharded(rr_context* ctx, uint32_t width, uint32_t height, co
                       (uint32_t*)d_tiles, (size_t)(frame_stride_bytes / 4));
 }
 
+int rr_render_orbit_sharded_lane(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispatch_params* params, float* angle,
+                                 float angle_step, uint32_t n_frames, uint32_t frames_per_dispatch, float fov_y, float aspect,
+                                 float zn, float zf, void* d_tiles, uint64_t frame_stride_bytes, uint32_t lane)
+{
+    if (int r = use_device(ctx)) return r;
+    if (lane >= rr_context::MAX_LANES) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_render_orbit_sharded_lane: lane out of range");
+    if (!ctx->lane_stream[lane]) {
+        RR_HIP(hipStreamCreateWithFlags(&ctx->lane_stream[lane], hipStreamNonBlocking));
+        RR_HIP(hipEventCreateWithFlags(&ctx->lane_fork[lane], hipEventDisableTiming));
+        RR_HIP(hipEventCreateWithFlags(&ctx->lane_done[lane], hipEventDisableTiming));
+    }
+    rr_dispatch_params p;
+    if (params) p = *params; else rr_default_dispatch_params(&p);
+    if (!(p.flags & RR_DISPATCH_KEEP_COUNTERS)) {      // zero the counters where every lane will see it: before the fork
+        RR_HIP(hipMemsetAsync(ctx->d_cnt, 0, sizeof(CounterBlock), ctx->stream));
+        ctx->accum_pixels = 0;
+        p.flags |= RR_DISPATCH_KEEP_COUNTERS;
+    }
+    // fork: the lane starts after everything submitted to the context's stream so far
+    RR_HIP(hipEventRecord(ctx->lane_fork[lane], ctx->stream));
+    RR_HIP(hipStreamWaitEvent(ctx->lane_stream[lane], ctx->lane_fork[lane], 0));
+    hipStream_t main_stream = ctx->stream;
+    CamDev* main_cams = ctx->d_cams;
+    size_t main_cap = ctx->cams_cap;
+    ctx->stream = ctx->lane_stream[lane];               // the lane has its own constant buffer: no reuse race between lanes
+    ctx->d_cams = ctx->lane_cams[lane];
+    ctx->cams_cap = ctx->lane_cams_cap[lane];
+    int rc = rr_render_orbit_sharded(ctx, width, height, &p, angle, angle_step, n_frames, frames_per_dispatch, fov_y, aspect, zn,
+                                     zf, d_tiles, frame_stride_bytes);
+    hipError_t e = rc == RR_OK ? hipEventRecord(ctx->lane_done[lane], ctx->stream) : hipSuccess;
+    ctx->lane_cams[lane] = ctx->d_cams;
+    ctx->lane_cams_cap[lane] = ctx->cams_cap;
+    ctx->stream = main_stream;
+    ctx->d_cams = main_cams;
+    ctx->cams_cap = main_cap;
+    if (rc != RR_OK) return rc;
+    if (e != hipSuccess) return fail(ctx, RR_ERR_DEVICE, "rr_render_orbit_sharded_lane: event", e);
+    ctx->lane_busy[lane] = true;
+    return RR_OK;
+}
+
 int rr_assemble_frames(rr_context* ctx, const void* d_gathered, uint32_t world, uint64_t rank_stride_bytes,
                        uint64_t frame_stride_bytes, uint32_t n_frames, uint32_t width, uint32_t height, void* d_frames,
                        uint64_t out_stride_bytes)
@@ -846,6 +928,7 @@ int rr_get_stats(rr_context* ctx, rr_stats* out)
 {
     if (int r = use_device(ctx)) return r;
     if (!out) return RR_ERR_INVALID_ARGUMENT;
+    if (int r = join_lanes(ctx)) return r;
     CounterBlock* h = (CounterBlock*)malloc(sizeof(CounterBlock));
     if (!h) return RR_ERR_OUT_OF_MEMORY;
     hipError_t e = hipMemcpyAsync(h, ctx->d_cnt, sizeof(CounterBlock), hipMemcpyDeviceToHost, ctx->stream);

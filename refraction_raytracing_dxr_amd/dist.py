@@ -79,15 +79,23 @@ def assemble_host(gathered, width, height, world):
 
 
 class ShardedFrames:
-    """Throughput path for N > 1: F frames per collective ("fewer, larger collectives"), two buffer
-    sets so that the gather of batch b runs on RCCL's stream while batch b+1 renders.
+    """Throughput path for N > 1: F frames per collective ("fewer, larger collectives").
 
-    Per batch and rank: F launches of the render kernel writing this rank's tiles straight into the
-    send buffer (rr_render_orbit_sharded), one gather to rank 0 (F * max_tiles * 4 KiB per rank),
-    and on rank 0 one de-interleave launch for the F frames of the previous batch.
+    Per batch and rank: one launch of the render kernel (F depth slices) writing this rank's tiles straight
+    into the send buffer (rr_render_orbit_sharded_lane), one gather to rank 0 (F * max_tiles * 4 KiB per
+    rank), and on rank 0 one de-interleave launch for the F frames.  Software pipeline over three buffer
+    sets and two render lanes:
+
+        launch(b)  ->  join(b-1), gather(b-1) on RCCL's stream  ->  wait gather(b-2), assemble(b-2)
+
+    so two render launches are always in flight (the tail of one overlaps the head of the next: a rank's
+    share of a launch is 1/world of the blocks, too few to hide the long-running waves on its own) and the
+    gather of a batch runs while the next two render.  launch(b) forks from the main stream after
+    assemble(b-3) was queued there, which is what frees buffer set b % 3.
     """
 
-    RING = 2
+    RING = 3
+    LANES = 2
 
     def __init__(self, renderer, width, height, rank, world, device, frames_per_gather=8):
         import torch
@@ -105,6 +113,7 @@ class ShardedFrames:
         # the most recent batch of assembled frames (rank 0)
         self.frames = torch.zeros(self.F * height * width * 4, dtype=torch.uint8, device=device) if rank == 0 else None
         self.last_batch = 0
+        self._on_frames = None
         self._via_host = world > 1 and dist.get_backend() == "gloo"     # test rigs without RCCL: stage through host
 
     def _gather(self, slot, nf):
@@ -135,35 +144,51 @@ class ShardedFrames:
             self.r.assemble_frames(self.recv[slot].data_ptr(), self.world, self.F * self.frame_bytes, self.frame_bytes,
                                    nf, self.width, self.height, self.frames.data_ptr(), self.height * self.width * 4)
             self.last_batch = nf
+            if self._on_frames is not None:     # consumer hook, ordered on the current stream (clone / encode / present)
+                self._on_frames(self.frames.view(self.F, self.height, self.width, 4)[:nf])
 
-    def render_orbit(self, n_frames, angle=0.01, angle_step=0.01, params=None):
+    def render_orbit(self, n_frames, angle=0.01, angle_step=0.01, params=None, on_frames=None):
         """Renders, gathers and assembles n_frames; returns the rays this rank traced (blocks at the end
-        to read the counter)."""
+        to read the counter).  on_frames(uint8 [nf, h, w, 4] device view), rank 0 only, is called once per
+        assembled batch in frame order; the view is overwritten by the next batch."""
+        self._on_frames = on_frames
         from .host import default_params
         from ._capi import DISPATCH_KEEP_COUNTERS
         base = params if params is not None else default_params()
-        pending = None
+        rendered = None        # (slot, nf, lane): launched, not yet joined / gathered
+        gathering = None       # (slot, nf, work): gather in flight
         done = 0
         b = 0
         while done < n_frames:
             nf = min(self.F, n_frames - done)
-            slot = b % self.RING
+            slot, lane = b % self.RING, b % self.LANES
             p = default_params()
             for f, _ in base._fields_:
                 setattr(p, f, getattr(base, f))
             if done > 0:
                 p.flags |= DISPATCH_KEEP_COUNTERS
             angle = self.r.render_orbit_sharded(self.width, self.height, nf, self.send[slot].data_ptr(), self.frame_bytes,
-                                                angle=angle, angle_step=angle_step, params=p, frames_per_dispatch=nf)
-            work = self._gather(slot, nf)
-            if pending is not None:
-                self._finish(pending)
-            pending = (slot, nf, work)
+                                                angle=angle, angle_step=angle_step, params=p, frames_per_dispatch=nf,
+                                                lane=lane)
+            if rendered is not None:
+                rendered, gathering = None, self._advance(rendered, gathering)
+            rendered = (slot, nf, lane)
             done += nf
             b += 1
-        if pending is not None:
-            self._finish(pending)
+        if rendered is not None:
+            gathering = self._advance(rendered, gathering)
+        if gathering is not None:
+            self._finish(gathering)
         return self.r.stats().rays
+
+    def _advance(self, rendered, gathering):
+        """join + gather the batch that was launched before the newest one; finish the one before that"""
+        slot, nf, lane = rendered
+        self.r.lane_join(lane)
+        work = self._gather(slot, nf)
+        if gathering is not None:
+            self._finish(gathering)
+        return (slot, nf, work)
 
     def frames_host(self):
         """rank 0: the last batch as uint8 [n, h, w, 4]"""

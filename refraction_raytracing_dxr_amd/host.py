@@ -233,15 +233,25 @@ class Renderer:
 
     def render_orbit_sharded(self, width, height, n_frames, tiles_ptr, frame_stride_bytes, angle=0.01,
                              angle_step=0.01, params=None, frames_per_dispatch=1, fov_y=FOV_Y, aspect=ASPECT, zn=1.0,
-                             zf=125.0):
+                             zf=125.0, lane=None):
+        """lane=None: on the context's stream.  lane=0..3: on that internal stream, not joined until lane_join(lane)."""
         p = params if params is not None else default_params()
         a = C.c_float(float(np.float32(angle)))
-        self._ck(self._L.rr_render_orbit_sharded(self._h, width, height, C.byref(p), C.byref(a),
-                                                 float(np.float32(angle_step)), n_frames, frames_per_dispatch, fov_y,
-                                                 aspect, zn, zf, C.c_void_p(tiles_ptr), frame_stride_bytes),
-                 "rr_render_orbit_sharded")
+        if lane is None:
+            self._ck(self._L.rr_render_orbit_sharded(self._h, width, height, C.byref(p), C.byref(a),
+                                                     float(np.float32(angle_step)), n_frames, frames_per_dispatch, fov_y,
+                                                     aspect, zn, zf, C.c_void_p(tiles_ptr), frame_stride_bytes),
+                     "rr_render_orbit_sharded")
+        else:
+            self._ck(self._L.rr_render_orbit_sharded_lane(self._h, width, height, C.byref(p), C.byref(a),
+                                                          float(np.float32(angle_step)), n_frames, frames_per_dispatch,
+                                                          fov_y, aspect, zn, zf, C.c_void_p(tiles_ptr), frame_stride_bytes,
+                                                          lane), "rr_render_orbit_sharded_lane")
         self.width, self.height = width, height
         return a.value
+
+    def lane_join(self, lane):
+        self._ck(self._L.rr_lane_join(self._h, lane), "rr_lane_join")
 
     def assemble_frames(self, gathered_ptr, world, rank_stride_bytes, frame_stride_bytes, n_frames, width, height,
                         frames_ptr, out_stride_bytes):

@@ -543,14 +543,17 @@ def _sharded_worker(rank, world, port, backend, out):
     r = rr.Renderer(0)
     r.set_stream(torch.cuda.current_stream().cuda_stream)
     r.load_scene(m.verts, m.indices, env)
-    W, H, K, F = 250, 130, 7, 3
+    W, H, K, F = 250, 130, 13, 2                   # 7 batches: every buffer set and both lanes are reused
     sf = rr.dist.ShardedFrames(r, W, H, rank, world, torch.device("cuda", 0), frames_per_gather=F)
-    rays = sf.render_orbit(K, angle=0.01, params=rr.default_params(max_refract=8))
+    seen = []
+    rays = sf.render_orbit(K, angle=0.01, params=rr.default_params(max_refract=8),
+                           on_frames=(lambda fr: seen.append(fr.clone())) if rank == 0 else None)
     tot = torch.tensor([rays], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tot)
     if rank == 0:
-        got = sf.frames_host()                     # the last batch: frames 6.. (K=7, F=3 -> batches 3,3,1)
+        got = sf.frames_host()                     # the last batch: frame 12 (K=13, F=2 -> batches 2,2,2,2,2,2,1)
+        allf = torch.cat(seen).cpu().numpy()
         r.set_tile_partition(0, 1)
         a = np.float32(0.01)
         ref_rays = 0
@@ -561,7 +564,8 @@ def _sharded_worker(rank, world, port, backend, out):
             frames.append(r.read_frame().copy())
             ref_rays += r.stats().rays
             a = np.float32(a + np.float32(0.01))
-        ok = len(got) == 1 and np.array_equal(got[0], frames[6]) and int(tot.item()) == ref_rays
+        ok = (len(got) == 1 and np.array_equal(got[0], frames[12]) and int(tot.item()) == ref_rays
+              and len(allf) == K and all(np.array_equal(allf[k], frames[k]) for k in range(K)))
         np.save(out, np.array([int(ok), len(got), int(tot.item()), ref_rays]))
     if world > 1:
         dist.barrier()
