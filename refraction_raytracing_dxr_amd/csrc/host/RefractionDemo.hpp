@@ -27,6 +27,8 @@ struct Options {
 
 int initialize(const Options& opt);       // RefractionDemo.cpp:513-553; returns rr_status
 int drawFrame();                          // RefractionDemo.cpp:557-612; returns rr_status
+// the frame loop as one call: no per-frame wait or read-back, `in_flight` launches overlapping (1..4)
+int pump(int n_frames, int frames_per_dispatch, int in_flight, rr_stats* stats);
 // the frame drawFrame just produced (RGBA8, width*height*4), i.e. what Present would have shown
 const std::vector<uint8_t>& backBuffer();
 rr_context* context();

@@ -90,6 +90,8 @@ struct rr_context {
     CamDev*     lane_cams[MAX_LANES] = {};
     size_t      lane_cams_cap[MAX_LANES] = {};
     bool        lane_busy[MAX_LANES] = {};
+    uint32_t    frames_in_flight = 1;    // rr_set_frames_in_flight: launches of rr_render_orbit that may overlap
+    size_t      frame_base = 0;          // element offset of the most recent dispatch inside d_rgba8 / d_f32
 
     // frame
     uint32_t W = 0, H = 0, frame_world = 0, frame_depth = 1;
@@ -343,6 +345,14 @@ int rr_wait(rr_context* ctx)
     return RR_OK;
 }
 
+int rr_set_frames_in_flight(rr_context* ctx, uint32_t n)
+{
+    if (int r = use_device(ctx)) return r;
+    if (n == 0 || n > rr_context::MAX_LANES) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_set_frames_in_flight: 1..4");
+    ctx->frames_in_flight = n;
+    return RR_OK;
+}
+
 int rr_lane_join(rr_context* ctx, uint32_t lane)
 {
     if (int r = use_device(ctx)) return r;
@@ -577,8 +587,38 @@ int ensure_cams(rr_context* ctx, size_t n)
 
 // DispatchRays(W, H, depth): slice f uses the constants d_cams[f] and writes to out + f*stride.
 // ext_tiles != null: compact tile output into caller memory with the given stride (sharded frames).
+int ensure_frame_buffers(rr_context* ctx, size_t elems, bool want_f32)
+{
+    if (elems > ctx->rgba_elems || !ctx->d_rgba8) {
+        RR_HIP(hipStreamSynchronize(ctx->stream));
+        dfree(ctx->d_rgba8);
+        ctx->rgba_elems = 0;
+        RR_HIP(hipMalloc(&ctx->d_rgba8, elems * 4));
+        ctx->rgba_elems = elems;
+    }
+    if (want_f32 && (elems > ctx->f32_elems || !ctx->d_f32)) {
+        RR_HIP(hipStreamSynchronize(ctx->stream));
+        dfree(ctx->d_f32);
+        ctx->f32_elems = 0;
+        RR_HIP(hipMalloc(&ctx->d_f32, elems * 16));
+        ctx->f32_elems = elems;
+    }
+    return RR_OK;
+}
+
+int ensure_lane(rr_context* ctx, uint32_t lane)
+{
+    if (ctx->lane_stream[lane]) return RR_OK;
+    RR_HIP(hipStreamCreateWithFlags(&ctx->lane_stream[lane], hipStreamNonBlocking));
+    RR_HIP(hipEventCreateWithFlags(&ctx->lane_fork[lane], hipEventDisableTiming));
+    RR_HIP(hipEventCreateWithFlags(&ctx->lane_done[lane], hipEventDisableTiming));
+    return RR_OK;
+}
+
+// out_slot: which of the frames_in_flight output regions of the internal frame buffer this dispatch writes
 int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t depth, const CamDev* d_cams,
-                  const rr_dispatch_params& p, uint32_t* ext_tiles, size_t ext_stride_elems, bool keep_counters)
+                  const rr_dispatch_params& p, uint32_t* ext_tiles, size_t ext_stride_elems, bool keep_counters,
+                  uint32_t out_slot = 0, uint32_t out_slot_depth = 0)
 {
     if (width == 0 || height == 0 || width > 32768 || height > 32768 || depth == 0 || depth > 65535)
         return fail(ctx, RR_ERR_INVALID_ARGUMENT, "dispatch: bad frame size or depth");
@@ -595,23 +635,9 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     const size_t slice_elems = compact ? (size_t)max_local * TILE * TILE : (size_t)width * height;
     const size_t stride = ext_tiles ? ext_stride_elems : slice_elems;
     if (ext_tiles && want_f32) return fail(ctx, RR_ERR_UNSUPPORTED, "dispatch: float output is not available for external tile buffers");
-    if (!ext_tiles) {
-        const size_t elems = slice_elems * depth;
-        if (elems > ctx->rgba_elems || !ctx->d_rgba8) {
-            RR_HIP(hipStreamSynchronize(ctx->stream));
-            dfree(ctx->d_rgba8);
-            ctx->rgba_elems = 0;
-            RR_HIP(hipMalloc(&ctx->d_rgba8, elems * 4));
-            ctx->rgba_elems = elems;
-        }
-        if (want_f32 && (elems > ctx->f32_elems || !ctx->d_f32)) {
-            RR_HIP(hipStreamSynchronize(ctx->stream));
-            dfree(ctx->d_f32);
-            ctx->f32_elems = 0;
-            RR_HIP(hipMalloc(&ctx->d_f32, elems * 16));
-            ctx->f32_elems = elems;
-        }
-    }
+    const size_t out_base = ext_tiles ? 0 : slice_elems * out_slot_depth * out_slot;
+    if (!ext_tiles)
+        if (int r = ensure_frame_buffers(ctx, out_base + slice_elems * depth, want_f32)) return r;
 
     SceneDev sc;
     fill_scene(ctx, sc);
@@ -629,8 +655,8 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     a.max_refract = p.max_refract; a.max_reflect = p.max_reflect;
     a.ior = p.ior; a.inv_ior = 1.0f / p.ior;
     a.tmin_p = p.tmin_primary; a.tmax_p = p.tmax_primary; a.tmin_s = p.tmin_secondary; a.tmax_s = p.tmax_secondary;
-    a.out_rgba8 = ext_tiles ? ext_tiles : ctx->d_rgba8;
-    a.out_f32 = want_f32 ? ctx->d_f32 : nullptr;
+    a.out_rgba8 = ext_tiles ? ext_tiles : ctx->d_rgba8 + out_base;
+    a.out_f32 = want_f32 ? ctx->d_f32 + out_base : nullptr;
     a.counters = ctx->d_cnt->counters;
     a.ray_shards = ctx->d_cnt->shards;
     a.error_flag = &ctx->d_cnt->error;
@@ -673,6 +699,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     }
     ctx->W = width; ctx->H = height; ctx->frame_world = ctx->tile_world; ctx->frame_depth = depth;
     ctx->have_f32 = want_f32; ctx->have_frame = ext_tiles == nullptr; ctx->have_assembled = false;
+    if (!ext_tiles) ctx->frame_base = out_base;
     ctx->last_stats = stats;
     // pixels actually owned by this rank (partial edge tiles counted exactly)
     uint64_t px = 0;
@@ -730,8 +757,8 @@ int rr_read_frame_slice(rr_context* ctx, uint32_t slice, uint8_t* rgba8, float* 
         if (ctx->frame_world != 1) return fail(ctx, RR_ERR_STATE, "rr_read_frame: sharded frame, gather + rr_assemble_tiles first");
         if (slice >= ctx->frame_depth) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_read_frame: slice beyond the dispatch depth");
         if (rgba32f && !ctx->have_f32) return fail(ctx, RR_ERR_STATE, "rr_read_frame: dispatch with RR_DISPATCH_FLOAT_OUTPUT");
-        if (rgba8) RR_HIP(hipMemcpyAsync(rgba8, ctx->d_rgba8 + slice * n, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (rgba32f) RR_HIP(hipMemcpyAsync(rgba32f, ctx->d_f32 + slice * n, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+        if (rgba8) RR_HIP(hipMemcpyAsync(rgba8, ctx->d_rgba8 + ctx->frame_base + slice * n, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (rgba32f) RR_HIP(hipMemcpyAsync(rgba32f, ctx->d_f32 + ctx->frame_base + slice * n, n * 16, hipMemcpyDeviceToHost, ctx->stream));
     }
     RR_HIP(hipStreamSynchronize(ctx->stream));
     uint32_t err = 0;
@@ -749,7 +776,7 @@ int rr_export_tiles(rr_context* ctx, void* d_dst)
     if (!ctx->have_frame || ctx->frame_world < 2) return fail(ctx, RR_ERR_STATE, "rr_export_tiles: no sharded frame");
     uint32_t tx, nt, local, mx;
     tile_counts(ctx->W, ctx->H, ctx->tile_rank, ctx->frame_world, tx, nt, local, mx);
-    RR_HIP(hipMemcpyAsync(d_dst, ctx->d_rgba8, (size_t)mx * TILE * TILE * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    RR_HIP(hipMemcpyAsync(d_dst, ctx->d_rgba8 + ctx->frame_base, (size_t)mx * TILE * TILE * 4, hipMemcpyDeviceToDevice, ctx->stream));
     return RR_OK;
 }
 
@@ -799,12 +826,51 @@ int orbit_impl(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispat
     ctx->cam = cams.back(); ctx->cam_set = true;
     if (int r = upload_cams(ctx, cams.data(), n_frames)) return r;
     const bool keep_first = (p.flags & RR_DISPATCH_KEEP_COUNTERS) != 0;
-    for (uint32_t k = 0; k < n_frames; k += batch) {
+    const uint32_t n_batches = (n_frames + batch - 1) / batch;
+    // frames in flight: consecutive launches go to alternating lanes so that the long-running waves at the end of
+    // one overlap the start of the next.  Not for timed dispatches (their durations must be exclusive).
+    uint32_t lanes = ctx->frames_in_flight < n_batches ? ctx->frames_in_flight : n_batches;
+    if ((p.flags & RR_DISPATCH_TIME_KERNEL) || getenv("RR_DEBUG_DIAG")) lanes = 1;
+    if (lanes <= 1) {
+        for (uint32_t k = 0; k < n_frames; k += batch) {
+            const uint32_t d = n_frames - k < batch ? n_frames - k : batch;
+            uint32_t* ext = ext_tiles ? ext_tiles + (size_t)k * ext_stride_elems : nullptr;
+            if (int rc = dispatch_impl(ctx, width, height, d, ctx->d_cams + k, p, ext, ext_stride_elems, k > 0 || keep_first)) return rc;
+        }
+        return RR_OK;
+    }
+    if (!ext_tiles) {        // all output regions exist before anything overlaps
+        uint32_t tiles_x, n_tiles, local, max_local;
+        if (width == 0 || height == 0 || width > 32768 || height > 32768) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "dispatch: bad frame size or depth");
+        tile_counts(width, height, ctx->tile_rank, ctx->tile_world, tiles_x, n_tiles, local, max_local);
+        const size_t slice_elems = ctx->tile_world > 1 ? (size_t)max_local * TILE * TILE : (size_t)width * height;
+        if (int r = ensure_frame_buffers(ctx, slice_elems * batch * lanes, (p.flags & RR_DISPATCH_FLOAT_OUTPUT) != 0)) return r;
+    }
+    if (!keep_first) {
+        RR_HIP(hipMemsetAsync(ctx->d_cnt, 0, sizeof(CounterBlock), ctx->stream));
+        ctx->accum_pixels = 0;
+    }
+    for (uint32_t l = 0; l < lanes; ++l) {
+        if (int r = ensure_lane(ctx, l)) return r;
+        if (ctx->lane_busy[l]) { RR_HIP(hipStreamWaitEvent(ctx->stream, ctx->lane_done[l], 0)); ctx->lane_busy[l] = false; }
+    }
+    RR_HIP(hipEventRecord(ctx->lane_fork[0], ctx->stream));          // after the constants upload and the counter reset
+    for (uint32_t l = 0; l < lanes; ++l) RR_HIP(hipStreamWaitEvent(ctx->lane_stream[l], ctx->lane_fork[0], 0));
+    hipStream_t main_stream = ctx->stream;
+    int rc = RR_OK;
+    for (uint32_t k = 0, b = 0; k < n_frames && rc == RR_OK; k += batch, ++b) {
         const uint32_t d = n_frames - k < batch ? n_frames - k : batch;
         uint32_t* ext = ext_tiles ? ext_tiles + (size_t)k * ext_stride_elems : nullptr;
-        if (int rc = dispatch_impl(ctx, width, height, d, ctx->d_cams + k, p, ext, ext_stride_elems, k > 0 || keep_first)) return rc;
+        ctx->stream = ctx->lane_stream[b % lanes];
+        rc = dispatch_impl(ctx, width, height, d, ctx->d_cams + k, p, ext, ext_stride_elems, true, b % lanes, batch);
+        ctx->stream = main_stream;
     }
-    return RR_OK;
+    for (uint32_t l = 0; l < lanes; ++l) {                          // join: the caller's stream is ordered after every lane
+        hipError_t e = hipEventRecord(ctx->lane_done[l], ctx->lane_stream[l]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->lane_done[l], 0);
+        if (e != hipSuccess && rc == RR_OK) rc = fail(ctx, RR_ERR_DEVICE, "render_orbit: lane join", e);
+    }
+    return rc;
 }
 
 } // namespace
@@ -838,11 +904,7 @@ int rr_render_orbit_sharded_lane(rr_context* ctx, uint32_t width, uint32_t heigh
 {
     if (int r = use_device(ctx)) return r;
     if (lane >= rr_context::MAX_LANES) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_render_orbit_sharded_lane: lane out of range");
-    if (!ctx->lane_stream[lane]) {
-        RR_HIP(hipStreamCreateWithFlags(&ctx->lane_stream[lane], hipStreamNonBlocking));
-        RR_HIP(hipEventCreateWithFlags(&ctx->lane_fork[lane], hipEventDisableTiming));
-        RR_HIP(hipEventCreateWithFlags(&ctx->lane_done[lane], hipEventDisableTiming));
-    }
+    if (int r = ensure_lane(ctx, lane)) return r;
     rr_dispatch_params p;
     if (params) p = *params; else rr_default_dispatch_params(&p);
     if (!(p.flags & RR_DISPATCH_KEEP_COUNTERS)) {      // zero the counters where every lane will see it: before the fork
@@ -856,9 +918,11 @@ int rr_render_orbit_sharded_lane(rr_context* ctx, uint32_t width, uint32_t heigh
     hipStream_t main_stream = ctx->stream;
     CamDev* main_cams = ctx->d_cams;
     size_t main_cap = ctx->cams_cap;
+    const uint32_t main_in_flight = ctx->frames_in_flight;
     ctx->stream = ctx->lane_stream[lane];               // the lane has its own constant buffer: no reuse race between lanes
     ctx->d_cams = ctx->lane_cams[lane];
     ctx->cams_cap = ctx->lane_cams_cap[lane];
+    ctx->frames_in_flight = 1;                          // a lane is one stream: its launches stay in order
     int rc = rr_render_orbit_sharded(ctx, width, height, &p, angle, angle_step, n_frames, frames_per_dispatch, fov_y, aspect, zn,
                                      zf, d_tiles, frame_stride_bytes);
     hipError_t e = rc == RR_OK ? hipEventRecord(ctx->lane_done[lane], ctx->stream) : hipSuccess;
@@ -867,6 +931,7 @@ int rr_render_orbit_sharded_lane(rr_context* ctx, uint32_t width, uint32_t heigh
     ctx->stream = main_stream;
     ctx->d_cams = main_cams;
     ctx->cams_cap = main_cap;
+    ctx->frames_in_flight = main_in_flight;
     if (rc != RR_OK) return rc;
     if (e != hipSuccess) return fail(ctx, RR_ERR_DEVICE, "rr_render_orbit_sharded_lane: event", e);
     ctx->lane_busy[lane] = true;

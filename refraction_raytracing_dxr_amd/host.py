@@ -250,6 +250,10 @@ class Renderer:
         self.width, self.height = width, height
         return a.value
 
+    def set_frames_in_flight(self, n):
+        """launches of render_orbit that may overlap (1 = the reference's one-at-a-time frame loop)"""
+        self._ck(self._L.rr_set_frames_in_flight(self._h, n), "rr_set_frames_in_flight")
+
     def lane_join(self, lane):
         self._ck(self._L.rr_lane_join(self._h, lane), "rr_lane_join")
 

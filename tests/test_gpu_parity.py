@@ -528,6 +528,20 @@ def test_orbit_loop_matches_draw_frame_sequence(gpu):
     assert gpu.stats().rays == total
     for k in range(6):
         assert np.array_equal(gpu.read_frame(slice=k), ref[k])
+    # overlapping launches (frames in flight): same frames, same counters, every lane and output region reused
+    for fl in (2, 3, 4):
+        gpu.set_frames_in_flight(fl)
+        gpu.render_orbit(W, H, 6, params=p, frames_per_dispatch=1)
+        assert np.array_equal(gpu.read_frame(), ref[5]) and gpu.stats().rays == total
+        gpu.render_orbit(W, H, 6, params=p, frames_per_dispatch=4)
+        assert np.array_equal(gpu.read_frame(slice=0), ref[4]) and np.array_equal(gpu.read_frame(slice=1), ref[5])
+        assert gpu.stats().rays == total
+        gpu.render_orbit(W, H, 5, params=rr.default_params(flags=rr.DISPATCH_FLOAT_OUTPUT), frames_per_dispatch=2)
+        rgba, f32 = gpu.read_frame(want_float=True)
+        assert np.array_equal(rgba, ref[4]) and np.all(f32[..., 3] == 1.0)
+    gpu.set_frames_in_flight(1)
+    with pytest.raises(rr.RRError):
+        gpu.set_frames_in_flight(5)
 
 
 # ------------------------------------------------------------------------------- N > 1 pipeline
@@ -685,6 +699,15 @@ def test_rrdemo_cli(tmp_path, env_png):
     sc = rr.camera_orbit(0.01)
     ref = s.render(np.array(sc.proj_inv, np.float32), np.array(sc.camera_loc, np.float32), 256, 192, O.default_params(use_bvh=1))
     assert np.abs(img.astype(int) - ref["rgba8"][..., :3].astype(int)).max() <= 1
+    # the loop without per-frame read-back (rr_render_orbit, overlapping launches): last frame == drawFrame's 7th
+    seq = subprocess.run([exe, "--mesh", O.asset("shell.obj"), "--env", str(hdr), "--size", "256x192", "--frames", "7",
+                          "--out", str(tmp_path / "s_%03d.ppm")], capture_output=True, text=True, timeout=120)
+    pump = subprocess.run([exe, "--mesh", O.asset("shell.obj"), "--env", str(hdr), "--size", "256x192", "--frames", "7", "--pump",
+                           "--frames-per-dispatch", "2", "--in-flight", "3", "--out", str(tmp_path / "p_%03d.ppm")],
+                          capture_output=True, text=True, timeout=120)
+    assert seq.returncode == 0 and pump.returncode == 0, pump.stderr
+    assert "7 frames of 256x192" in pump.stdout and "3 in flight" in pump.stdout
+    assert open(tmp_path / "p_006.ppm", "rb").read() == open(tmp_path / "s_006.ppm", "rb").read()
     bad = subprocess.run([exe, "--mesh", str(tmp_path / "missing.obj"), "--env", str(hdr)], capture_output=True, text=True)
     assert bad.returncode == 1 and "mesh could not be loaded" in bad.stderr
 
