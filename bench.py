@@ -31,12 +31,13 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
 def algorithmic_bytes(st):
-    """Bytes the traversal/shading must touch (DESIGN.md 'Algorithmic bytes'): 64 B per internal node
-    visit, 48 B per triangle test, 36 B of vertex normals per shaded hit, 12 B env texel per miss,
-    4 B RGBA8 per pixel.  (SURVEY 8d additionally prices a ray queue and a float accumulator; the
-    fused kernel has neither, so they are left out -- this is the conservative figure.)"""
+    """Bytes the traversal/shading must touch (DESIGN.md 'Algorithmic bytes'), priced with the record sizes the
+    kernel really reads: 32 B per internal node visit (QNode: both child boxes on a 16-bit grid + child refs),
+    48 B per triangle test, 36 B of vertex normals per shaded hit, 12 B env texel per miss, 4 B RGBA8 per
+    pixel.  (SURVEY 8d prices a node at 64 B (fp32 boxes) and adds a ray queue and a float accumulator the
+    fused kernel does not have; that figure is reported next to this one as survey_formula_bytes_per_ray.)"""
     shaded = st.hits - st.terminal_hits
-    return 64 * st.node_visits + 48 * st.tri_tests + 36 * shaded + 12 * st.misses + 4 * st.pixels
+    return 32 * st.node_visits + 48 * st.tri_tests + 36 * shaded + 12 * st.misses + 4 * st.pixels
 
 
 def survey_formula_bytes(st):
@@ -89,6 +90,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--depth1", action="store_true", help="also time the reference's shape, one DispatchRays per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-subdiv", action="store_true",
+                    help="skip the second figure (15 472-triangle monkey); profiling runs use this so that every "
+                         "k_render_fused launch in the trace is a launch of the headline workload")
     ap.add_argument("--frames-per-dispatch", type=int, default=64,
                     help="depth slices per launch (DispatchRays(W,H,Depth)); N>1: also frames per RCCL gather")
     args = ap.parse_args()
@@ -204,7 +208,7 @@ def main():
                     "tri_tests_per_ray": round(sst.tri_tests / sst.rays, 2),
                     "kernel_grays_per_s": round(sst.rays / kn / (kernel_us * 1e-6) / 1e9, 3)}
         # ---- BASELINE's "~16k tri Suzanne": monkey.obj midpoint-subdivided twice (15 472 tri), same frames ----
-        if world == 1:
+        if world == 1 and not args.no_subdiv:
             from refraction_raytracing_dxr_amd.synth import subdivide
             v16, i16 = subdivide(mesh.verts, 2)
             r.load_scene(v16, i16, env)

@@ -439,14 +439,34 @@ __global__ __launch_bounds__(256) void k_pack_tris(const float* __restrict__ ver
     nrms[i] = m;
 }
 
-__global__ __launch_bounds__(256) void k_rebase_nodes(BvhNode* __restrict__ dst, const BvhNode* __restrict__ src, uint32_t n,
-                                                      uint32_t node_off, uint32_t tri_off)
+// fp32 node -> traversal node on the 16-bit grid g.  lo planes: floor - 1, hi planes: ceil + 1 (the fp32
+// rounding of (v - org)/cell is below 0.02 cells at 65535), clamped to the grid; child refs optionally rebased
+// into the scene pool.
+__device__ __forceinline__ uint32_t q_lo(float v, float org, float cell)
+{
+    const float x = floorf((v - org) / cell) - 1.0f;
+    return (uint32_t)fminf(fmaxf(x, 0.0f), 65535.0f);          // NaN/-inf -> 0, +inf -> 65535
+}
+__device__ __forceinline__ uint32_t q_hi(float v, float org, float cell)
+{
+    const float x = ceilf((v - org) / cell) + 1.0f;
+    return (uint32_t)fmaxf(fminf(x, 65535.0f), 0.0f);
+}
+__global__ __launch_bounds__(256) void k_quantize_nodes(QNode* __restrict__ dst, const BvhNode* __restrict__ src, uint32_t n, QGrid g,
+                                                        uint32_t node_off, uint32_t tri_off)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    BvhNode nd = src[i];
-    for (int k = 0; k < 2; ++k) nd.c[k] = nd.c[k] >= 0 ? nd.c[k] + (int)node_off : ~(int)((uint32_t)~nd.c[k] + tri_off);
-    dst[i] = nd;
+    const BvhNode s = src[i];
+    QNode q;
+    q.lox = q_lo(s.lox[0], g.org[0], g.cell[0]) | (q_lo(s.lox[1], g.org[0], g.cell[0]) << 16);
+    q.loy = q_lo(s.loy[0], g.org[1], g.cell[1]) | (q_lo(s.loy[1], g.org[1], g.cell[1]) << 16);
+    q.loz = q_lo(s.loz[0], g.org[2], g.cell[2]) | (q_lo(s.loz[1], g.org[2], g.cell[2]) << 16);
+    q.hix = q_hi(s.hix[0], g.org[0], g.cell[0]) | (q_hi(s.hix[1], g.org[0], g.cell[0]) << 16);
+    q.hiy = q_hi(s.hiy[0], g.org[1], g.cell[1]) | (q_hi(s.hiy[1], g.org[1], g.cell[1]) << 16);
+    q.hiz = q_hi(s.hiz[0], g.org[2], g.cell[2]) | (q_hi(s.hiz[1], g.org[2], g.cell[2]) << 16);
+    for (int k = 0; k < 2; ++k) q.c[k] = s.c[k] >= 0 ? s.c[k] + (int)node_off : ~(int)((uint32_t)~s.c[k] + tri_off);
+    dst[i] = q;
 }
 
 __global__ __launch_bounds__(256) void k_env_pad(const float* __restrict__ rgb, float4* __restrict__ out, uint32_t n)
@@ -519,10 +539,11 @@ hipError_t launch_pack_tris(const void* verts, const uint32_t* idx, const BuildB
     return hipGetLastError();
 }
 
-hipError_t launch_rebase_nodes(BvhNode* dst, const BvhNode* src, uint32_t n_nodes, uint32_t node_off, uint32_t tri_off, hipStream_t s)
+hipError_t launch_quantize_nodes(QNode* dst, const BvhNode* src, uint32_t n_nodes, const QGrid& g, uint32_t node_off, uint32_t tri_off,
+                                 hipStream_t s)
 {
     if (n_nodes == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_rebase_nodes, dim3(cdiv(n_nodes, 256u)), dim3(256), 0, s, dst, src, n_nodes, node_off, tri_off);
+    hipLaunchKernelGGL(k_quantize_nodes, dim3(cdiv(n_nodes, 256u)), dim3(256), 0, s, dst, src, n_nodes, g, node_off, tri_off);
     return hipGetLastError();
 }
 

@@ -33,7 +33,9 @@ struct MeshRes {
     float*    d_verts = nullptr;     // n_verts * 8 floats
     uint32_t* d_idx = nullptr;
     uint32_t  n_verts = 0, n_idx = 0, n_tris = 0;
-    BvhNode*  nodes = nullptr;
+    BvhNode*  nodes = nullptr;       // fp32 hierarchy (builder output, rr_download_blas)
+    QNode*    qnodes = nullptr;      // what traversal reads: the same nodes on the 16-bit grid of the bounds
+    QGrid     grid = { { 0, 0, 0 }, { 1, 1, 1 } };
     TriRec*   tris = nullptr;
     NrmRec*   nrms = nullptr;
     bool      built = false;
@@ -67,7 +69,9 @@ struct rr_context {
     // TLAS
     std::vector<rr_instance_desc> inst_host;
     InstDev* d_insts = nullptr;
-    BvhNode* d_pool_nodes = nullptr;   // flattened scene: TLAS nodes, then every BLAS in use
+    BvhNode* d_pool_nodes = nullptr;   // fp32 TLAS nodes (builder output)
+    QNode*   d_pool_qnodes = nullptr;  // flattened scene as traversal reads it: TLAS nodes, then every BLAS in use
+    QGrid    scene_grid = { { 0, 0, 0 }, { 1, 1, 1 } };
     TriRec*  d_pool_tris = nullptr;
     NrmRec*  d_pool_nrms = nullptr;
     uint32_t n_pool_tris = 0;
@@ -206,16 +210,30 @@ int use_device(rr_context* ctx)
     return RR_OK;
 }
 
+// 16-bit grid over a box {lo[3], hi[3]}: 65530 cells span the extent, so ceil+1 of the upper bound stays
+// on the grid; a flat axis gets a tiny positive cell
+QGrid make_grid(const float b[6])
+{
+    QGrid g;
+    for (int k = 0; k < 3; ++k) {
+        const float ext = b[3 + k] - b[k];
+        const float mag = std::max(std::max(std::fabs(b[k]), std::fabs(b[3 + k])), 1e-30f);
+        g.org[k] = b[k];
+        g.cell[k] = std::max(ext, mag * 1e-6f) / 65530.0f;
+    }
+    return g;
+}
+
 void fill_scene(const rr_context* ctx, SceneDev& sc)
 {
     memset(&sc, 0, sizeof sc);
     const MeshRes* m0 = nullptr;
     if (ctx->single_identity) m0 = &ctx->meshes[(size_t)ctx->inst_host[0].blas];
     if (m0) {
-        sc.blas0.nodes = m0->nodes; sc.blas0.tris = m0->tris; sc.blas0.nrms = m0->nrms;
+        sc.blas0.nodes = m0->qnodes; sc.blas0.grid = m0->grid; sc.blas0.tris = m0->tris; sc.blas0.nrms = m0->nrms;
         sc.blas0.n_tris = m0->n_tris; sc.blas0.depth = m0->depth; sc.blas0.scale = m0->scale;
     }
-    sc.pool_nodes = ctx->d_pool_nodes; sc.pool_tris = ctx->d_pool_tris; sc.pool_nrms = ctx->d_pool_nrms;
+    sc.pool_nodes = ctx->d_pool_qnodes; sc.grid = ctx->scene_grid; sc.pool_tris = ctx->d_pool_tris; sc.pool_nrms = ctx->d_pool_nrms;
     sc.insts = ctx->d_insts;
     sc.n_insts = ctx->n_insts;
     sc.n_pool_tris = ctx->n_pool_tris;
@@ -295,8 +313,8 @@ int rr_destroy(rr_context* ctx)
         (void)hipEventDestroy(ctx->lane_done[l]);
         dfree(ctx->lane_cams[l]);
     }
-    for (MeshRes& m : ctx->meshes) { dfree(m.d_verts); dfree(m.d_idx); dfree(m.nodes); dfree(m.tris); dfree(m.nrms); }
-    dfree(ctx->d_env); dfree(ctx->d_insts); dfree(ctx->d_pool_nodes); dfree(ctx->d_pool_tris); dfree(ctx->d_pool_nrms); dfree(ctx->d_rgba8); dfree(ctx->d_f32);
+    for (MeshRes& m : ctx->meshes) { dfree(m.d_verts); dfree(m.d_idx); dfree(m.nodes); dfree(m.qnodes); dfree(m.tris); dfree(m.nrms); }
+    dfree(ctx->d_env); dfree(ctx->d_insts); dfree(ctx->d_pool_nodes); dfree(ctx->d_pool_qnodes); dfree(ctx->d_pool_tris); dfree(ctx->d_pool_nrms); dfree(ctx->d_rgba8); dfree(ctx->d_f32);
     dfree(ctx->d_assembled); dfree(ctx->d_cnt); dfree(ctx->d_rays); dfree(ctx->d_hits); dfree(ctx->d_cams);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
@@ -416,9 +434,10 @@ int rr_build_blas_ex(rr_context* ctx, uint32_t mesh_id, uint32_t flags)
     const uint32_t n = m.n_tris;
     BuildScratch s;
     if (int r = alloc_build(ctx, n, s)) return r;
-    dfree(m.nodes); dfree(m.tris); dfree(m.nrms);
+    dfree(m.nodes); dfree(m.qnodes); dfree(m.tris); dfree(m.nrms);
     m.built = false;
     RR_HIP(hipMalloc(&m.nodes, (size_t)(n > 1 ? n - 1 : 1) * sizeof(BvhNode)));
+    RR_HIP(hipMalloc(&m.qnodes, (size_t)(n > 1 ? n - 1 : 1) * sizeof(QNode)));
     RR_HIP(hipMalloc(&m.tris, (size_t)n * sizeof(TriRec)));
     RR_HIP(hipMalloc(&m.nrms, (size_t)n * sizeof(NrmRec)));
     s.b.nodes = m.nodes;
@@ -436,6 +455,8 @@ int rr_build_blas_ex(rr_context* ctx, uint32_t mesh_id, uint32_t flags)
     m.scale = 0.0f;
     for (int k = 0; k < 6; ++k) m.scale = std::max(m.scale, std::fabs(m.bounds[k]));
     m.depth = depth;
+    m.grid = make_grid(m.bounds);
+    RR_HIP(launch_quantize_nodes(m.qnodes, m.nodes, n > 1 ? n - 1 : 1, m.grid, 0, 0, ctx->stream));
     if (depth > 64) return fail(ctx, RR_ERR_UNSUPPORTED, "rr_build_blas: LBVH deeper than the 64-entry traversal stack");
     m.built = true;
     ctx->tlas_built = false;      // any TLAS built before refers to the old BLAS
@@ -481,6 +502,7 @@ int rr_build_tlas(rr_context* ctx, const rr_instance_desc* instances, uint32_t n
         }
         o.root = node_off[(size_t)d.blas];
         o.scale = m.scale;
+        o.grid = m.grid;
         for (int c = 0; c < 8; ++c) {       // world-space extent of the instance (for the TLAS box padding)
             const float x = (c & 1) ? m.bounds[3] : m.bounds[0], y = (c & 2) ? m.bounds[4] : m.bounds[1], z = (c & 4) ? m.bounds[5] : m.bounds[2];
             for (int r = 0; r < 3; ++r)
@@ -492,9 +514,10 @@ int rr_build_tlas(rr_context* ctx, const rr_instance_desc* instances, uint32_t n
         memcpy(&xb[(size_t)n * 12 + (size_t)i * 6], m.bounds, 24);
     }
     ctx->tlas_built = false;
-    dfree(ctx->d_insts); dfree(ctx->d_pool_nodes); dfree(ctx->d_pool_tris); dfree(ctx->d_pool_nrms);
+    dfree(ctx->d_insts); dfree(ctx->d_pool_nodes); dfree(ctx->d_pool_qnodes); dfree(ctx->d_pool_tris); dfree(ctx->d_pool_nrms);
     RR_HIP(hipMalloc(&ctx->d_insts, (size_t)n * sizeof(InstDev)));
-    RR_HIP(hipMalloc(&ctx->d_pool_nodes, (size_t)n_pool_nodes * sizeof(BvhNode)));
+    RR_HIP(hipMalloc(&ctx->d_pool_nodes, (size_t)n_tlas * sizeof(BvhNode)));
+    RR_HIP(hipMalloc(&ctx->d_pool_qnodes, (size_t)n_pool_nodes * sizeof(QNode)));
     RR_HIP(hipMalloc(&ctx->d_pool_tris, (size_t)n_pool_tris * sizeof(TriRec)));
     RR_HIP(hipMalloc(&ctx->d_pool_nrms, (size_t)n_pool_tris * sizeof(NrmRec)));
     float* d_xb = nullptr;
@@ -512,10 +535,24 @@ int rr_build_tlas(rr_context* ctx, const rr_instance_desc* instances, uint32_t n
         if (e == hipSuccess) e = launch_inst_setup(ctx->d_insts, d_xb, n, s.b, ctx->stream);
         if (e == hipSuccess) e = launch_lbvh(s.b, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(&depth, s.b.depth, 4, hipMemcpyDeviceToHost, ctx->stream);
+        // scene grid = the box of the TLAS root (node 0 holds the boxes of its two children)
+        BvhNode root;
+        if (e == hipSuccess) e = hipMemcpyAsync(&root, ctx->d_pool_nodes, sizeof root, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) {
+            float sb[6] = { 3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f };
+            for (int k = 0; k < 2; ++k) {
+                if (!(root.lox[k] <= root.hix[k])) continue;           // the empty second child of a one-instance TLAS
+                sb[0] = std::min(sb[0], root.lox[k]); sb[1] = std::min(sb[1], root.loy[k]); sb[2] = std::min(sb[2], root.loz[k]);
+                sb[3] = std::max(sb[3], root.hix[k]); sb[4] = std::max(sb[4], root.hiy[k]); sb[5] = std::max(sb[5], root.hiz[k]);
+            }
+            ctx->scene_grid = make_grid(sb);
+            e = launch_quantize_nodes(ctx->d_pool_qnodes, ctx->d_pool_nodes, n_tlas, ctx->scene_grid, 0, 0, ctx->stream);
+        }
         for (size_t mi = 0; mi < ctx->meshes.size() && e == hipSuccess; ++mi) {
             if (node_off[mi] == 0xffffffffu) continue;
             const MeshRes& m = ctx->meshes[mi];
-            e = launch_rebase_nodes(ctx->d_pool_nodes + node_off[mi], m.nodes, m.n_tris > 1 ? m.n_tris - 1 : 1, node_off[mi], tri_off[mi], ctx->stream);
+            e = launch_quantize_nodes(ctx->d_pool_qnodes + node_off[mi], m.nodes, m.n_tris > 1 ? m.n_tris - 1 : 1, m.grid, node_off[mi], tri_off[mi], ctx->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_pool_tris + tri_off[mi], m.tris, (size_t)m.n_tris * sizeof(TriRec), hipMemcpyDeviceToDevice, ctx->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_pool_nrms + tri_off[mi], m.nrms, (size_t)m.n_tris * sizeof(NrmRec), hipMemcpyDeviceToDevice, ctx->stream);
         }

@@ -111,62 +111,92 @@ constexpr uint32_t CULL_BACK = 0x10u, CULL_FRONT = 0x20u;
 // ---- box-test ray setup ----------------------------------------------------------------------------
 // The box test is exempt from the arithmetic contract: it only has to be CONSERVATIVE (never cull a
 // box that holds a triangle the exact-order triangle test would accept).  Slabs are evaluated as
-// t = fma(plane, inv, -(O*inv)) with a hardware reciprocal; the rounding of that form
-// (<= |t|*2^-22 + |O*inv|*2^-24) is covered by moving the near planes earlier and the far planes later
-// by pad = |O*inv|*2^-22 + |inv|*eps_w (i.e. the box grows by eps_w world units, see box_ray), folded
-// into the per-ray constants, plus a relative 2^-20 on t_far.  A (nearly) zero direction component
+// t = fma(q, cell*inv, (org-O)*inv) with a hardware reciprocal.  With oi = (org-O)*inv the computed t is
+// within (|q*cell*inv| + |oi|) * (2^-22 + 2^-23) of the exact slab distance (reciprocal, the two products, the
+// fma); |q*cell| <= extent, so moving the near planes earlier and the far planes later by
+// pad = |oi|*1e-6 + |inv|*eps_w (the box grows by eps_w >= 5e-6*extent world units, see box_ray), folded into
+// the per-ray constants, covers it with a wide margin and the test is a plain tn <= tf.  A (nearly) zero direction component
 // gets inv = +-1e20: pad is then huge, so the slab on that axis only rejects origins clearly outside
 // it -- rays lying exactly in a box face stay conservative.
+//
+// Planes come from the 16-bit grid of the BLAS (QGrid): plane = org + q*cell, so
+// t = q*(cell*inv) + (org - O)*inv; the extra rounding of cell*inv (<= extent*|inv|*2^-24) is far inside
+// the |inv|*eps_w term (eps_w >= 1e-5 * largest |coordinate| >= 5e-6 * extent).
 struct BoxRay {
-    f3 inv;        // 1/D (approximate)
-    f3 klo, khi;   // additive constants for the lo / hi planes: -(O*inv) -/+ sign(inv)*pad
+    f3 inv;          // cell/D (approximate): t per grid step
+    f3 kn, kf;       // additive constants of the near / far plane of each axis: (org-O)/D -/+ pad
+    bool sx, sy, sz; // D < 0 on that axis: the hi plane is the near one
 };
-__device__ __forceinline__ void box_axis(float o, float d, float eps_w, float& inv, float& klo, float& khi)
+__device__ __forceinline__ void box_axis(float o, float d, float eps_w, float org, float cell, float& inv_g, float& kn, float& kf, bool& neg)
 {
     const float dg = fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d;
-    inv = __builtin_amdgcn_rcpf(dg);
-    const float oi = -(o * inv);
-    const float pad = copysignf(fmaf(fabsf(oi), 2.4e-7f, fabsf(inv) * eps_w), inv);
-    klo = oi - pad;
-    khi = oi + pad;
+    const float inv = __builtin_amdgcn_rcpf(dg);
+    const float oi = (org - o) * inv;
+    const float pad = fmaf(fabsf(oi), 1e-6f, fabsf(inv) * eps_w);
+    kn = oi - pad;
+    kf = oi + pad;
+    inv_g = inv * cell;
+    neg = inv < 0.0f;
 }
 // scene_scale: largest |coordinate| of the geometry the ray is traced against.  Boxes are grown by
 // 1e-5 of the larger of that and the ray origin's magnitude: the fp32 triangle test accepts points
 // a few ulps outside a triangle's edge (e.g. a ray running exactly along the symmetry plane of a
 // mirrored mesh, hitting the shared edges), and the box test must not cull those.
-__device__ __forceinline__ BoxRay box_ray(f3 O, f3 D, float scene_scale)
+__device__ __forceinline__ BoxRay box_ray(f3 O, f3 D, float scene_scale, const QGrid& g)
 {
     const float eps_w = 1e-5f * fmaxf(fmaxf(fabsf(O.x), fabsf(O.y)), fmaxf(fabsf(O.z), scene_scale));
     BoxRay r;
-    box_axis(O.x, D.x, eps_w, r.inv.x, r.klo.x, r.khi.x);
-    box_axis(O.y, D.y, eps_w, r.inv.y, r.klo.y, r.khi.y);
-    box_axis(O.z, D.z, eps_w, r.inv.z, r.klo.z, r.khi.z);
+    box_axis(O.x, D.x, eps_w, g.org[0], g.cell[0], r.inv.x, r.kn.x, r.kf.x, r.sx);
+    box_axis(O.y, D.y, eps_w, g.org[1], g.cell[1], r.inv.y, r.kn.y, r.kf.y, r.sy);
+    box_axis(O.z, D.z, eps_w, g.org[2], g.cell[2], r.inv.z, r.kn.z, r.kf.z, r.sz);
     return r;
 }
+
+// a QNode as traversal loads it: two 16-byte requests
+struct NodeQ { uint4 a, b; };
+__device__ __forceinline__ NodeQ load_node(const QNode* __restrict__ nodes, int node)
+{
+    const uint4* q = reinterpret_cast<const uint4*>(nodes) + (uint32_t)node * 2u;
+    NodeQ n;
+    n.a = q[0]; n.b = q[1];
+    return n;
+}
+
 
 constexpr int TRAV_DONE = (int)0x80000000;     // neither an internal index (>= 0) nor a leaf (~i with i < 2^31-1)
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f splat2(float x) { v2f r = { x, x }; return r; }
 __device__ __forceinline__ v2f mk2(float x, float y) { v2f r = { x, y }; return r; }
+__device__ __forceinline__ v2f unpack2(uint32_t w) { return mk2((float)(w & 0xffffu), (float)(w >> 16)); }
 
-// slab test of BOTH children of a node (q0,q1,q2 = the node's first three 16-byte words);
-// six v_pk_fma_f32 give the twelve plane distances, tn0/tn1 are the entry distances
-__device__ __forceinline__ void box2_hit(const BoxRay& r, const float4 q0, const float4 q1, const float4 q2, float tmin, float tmax,
+// raw min/max instructions (IEEE minNum/maxNum of their operands; written as asm so that the compiler does not
+// add a canonicalising v_max x,x per operand per trip)
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmax2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin2(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// slab test of BOTH children of a node.  The ray's direction signs say which plane of each axis is the near
+// one, so six selects on the packed words (both children at once) replace the min/max of the slab test;
+// then twelve u16 -> f32 conversions (SDWA selects the half word) and six v_pk_fma_f32 give the near and far
+// distances of both children, tn0/tn1 are the entry distances.
+__device__ __forceinline__ void box2_hit(const BoxRay& r, const NodeQ& n, float tmin, float tmax,
                                          bool& h0, bool& h1, float& tn0, float& tn1)
 {
-    const v2f ax = __builtin_elementwise_fma(mk2(q0.x, q0.y), splat2(r.inv.x), splat2(r.klo.x));
-    const v2f ay = __builtin_elementwise_fma(mk2(q0.z, q0.w), splat2(r.inv.y), splat2(r.klo.y));
-    const v2f az = __builtin_elementwise_fma(mk2(q1.x, q1.y), splat2(r.inv.z), splat2(r.klo.z));
-    const v2f bx = __builtin_elementwise_fma(mk2(q1.z, q1.w), splat2(r.inv.x), splat2(r.khi.x));
-    const v2f by = __builtin_elementwise_fma(mk2(q2.x, q2.y), splat2(r.inv.y), splat2(r.khi.y));
-    const v2f bz = __builtin_elementwise_fma(mk2(q2.z, q2.w), splat2(r.inv.z), splat2(r.khi.z));
-    tn0 = fmaxf(fmaxf(fmaxf(fminf(ax.x, bx.x), fminf(ay.x, by.x)), fminf(az.x, bz.x)), tmin);
-    tn1 = fmaxf(fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fminf(az.y, bz.y)), tmin);
-    const float tf0 = fminf(fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x)), tmax);
-    const float tf1 = fminf(fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fmaxf(az.y, bz.y)), tmax);
-    h0 = tn0 <= tf0 * 1.000001f;
-    h1 = tn1 <= tf1 * 1.000001f;
+    const uint32_t lox = n.a.x, loy = n.a.y, loz = n.a.z, hix = n.a.w, hiy = n.b.x, hiz = n.b.y;
+    const v2f nx = __builtin_elementwise_fma(unpack2(r.sx ? hix : lox), splat2(r.inv.x), splat2(r.kn.x));
+    const v2f ny = __builtin_elementwise_fma(unpack2(r.sy ? hiy : loy), splat2(r.inv.y), splat2(r.kn.y));
+    const v2f nz = __builtin_elementwise_fma(unpack2(r.sz ? hiz : loz), splat2(r.inv.z), splat2(r.kn.z));
+    const v2f fx = __builtin_elementwise_fma(unpack2(r.sx ? lox : hix), splat2(r.inv.x), splat2(r.kf.x));
+    const v2f fy = __builtin_elementwise_fma(unpack2(r.sy ? loy : hiy), splat2(r.inv.y), splat2(r.kf.y));
+    const v2f fz = __builtin_elementwise_fma(unpack2(r.sz ? loz : hiz), splat2(r.inv.z), splat2(r.kf.z));
+    tn0 = vmax2(vmax3(nx.x, ny.x, nz.x), tmin);
+    tn1 = vmax2(vmax3(nx.y, ny.y, nz.y), tmin);
+    const float tf0 = vmin2(vmin3(fx.x, fy.x, fz.x), tmax);
+    const float tf1 = vmin2(vmin3(fx.y, fy.y, fz.y), tmax);
+    h0 = tn0 <= tf0;
+    h1 = tn1 <= tf1;
 }
 
 // per-lane traversal stack in LDS, column layout (entry e of lane l at base[e*64 + l]: conflict-free)
@@ -185,13 +215,13 @@ struct Stack16 {
 // one traversal step at an internal node: returns the next node (near child, or a popped entry, or
 // TRAV_DONE) and pushes the far child when both are hit.  stk: this lane's LDS column, sp0: stack floor.
 template <bool CHECK, class StackT>
-__device__ __forceinline__ int node_step(const BoxRay& br, const float4 q0, const float4 q1, const float4 q2, const float4 q3,
+__device__ __forceinline__ int node_step(const BoxRay& br, const NodeQ& n,
                                          float tmin, float tmax, const StackT stk, int& sp, int sp0, int cap, uint32_t& err)
 {
     bool h0, h1;
     float tn0, tn1;
-    box2_hit(br, q0, q1, q2, tmin, tmax, h0, h1, tn0, tn1);
-    const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+    box2_hit(br, n, tmin, tmax, h0, h1, tn0, tn1);
+    const int c0 = (int)n.b.z, c1 = (int)n.b.w;
     const bool both = h0 && h1, swap = tn1 < tn0;
     const int nearc = (h0 && !(h1 && swap)) ? c0 : c1;
     int next = (h0 || h1) ? nearc : TRAV_DONE;
@@ -250,17 +280,22 @@ __device__ __forceinline__ void trace_blas(const BlasDev& bl, f3 O, f3 D, float 
                                            HitRec& best, const StackT stk, int sp0, uint32_t* err, TravCounters& cnt,
                                            const Diag dg = Diag{ nullptr })
 {
-    const BoxRay br = box_ray(O, D, bl.scale);
-    const float4* __restrict__ nodes = reinterpret_cast<const float4*>(bl.nodes);
+    const BoxRay br = box_ray(O, D, bl.scale, bl.grid);
+    const QNode* __restrict__ nodes = bl.nodes;
     int sp = sp0;
     int node = 0;
     for (;;) {
         while (node >= 0) {
             diag_trip(dg);
-            const float4* q = nodes + (uint32_t)node * 4u;
-            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            const NodeQ q = load_node(nodes, node);
             if (STATS) cnt.nodes++;
-            node = node_step<true>(br, q0, q1, q2, q3, tmin, best.t, stk, sp, sp0, STACK, *err);
+            node = node_step<true>(br, q, tmin, best.t, stk, sp, sp0, STACK, *err);
+#ifdef RR_EXP_EXTRA_VALU      // experiment: what do N more VALU instructions per visit cost?
+            { float dv = br.inv.x;
+#pragma unroll
+              for (int k = 0; k < RR_EXP_EXTRA_VALU; ++k) asm volatile("v_add_f32 %0, %0, %0" : "+v"(dv));
+              asm volatile("" :: "v"(dv)); }
+#endif
         }
         if (node == TRAV_DONE) break;
         diag_trip(dg, 1);
@@ -298,25 +333,24 @@ __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, floa
         trace_blas<STACK, STATS>(sc.blas0, O, D, tmin, flags, 0u, best, Stack32{ stk }, 0, err, cnt, dg);
         return;
     }
-    const float4* __restrict__ nodes = reinterpret_cast<const float4*>(sc.pool_nodes);
+    const QNode* __restrict__ nodes = sc.pool_nodes;
     const Stack32 st{ stk };
     constexpr uint32_t NO_INST = 0xffffffffu;
-    BoxRay br = box_ray(O, D, sc.scale);
+    BoxRay br = box_ray(O, D, sc.scale, sc.grid);
     f3 Oc = O, Dc = D;                      // the ray in the space of the level being walked
     uint32_t cull = flags, cur = NO_INST;
     int sp = 0, floor = 0, node = 0;        // floor: stack level at which the current instance was entered
     uint32_t e = 0;
     for (;;) {
         while (node >= 0) {
-            const float4* q = nodes + (uint32_t)node * 4u;
-            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            const NodeQ q = load_node(nodes, node);
             if (STATS) cnt.nodes++;
-            node = node_step<true>(br, q0, q1, q2, q3, tmin, best.t, st, sp, floor, STACK, e);
+            node = node_step<true>(br, q, tmin, best.t, st, sp, floor, STACK, e);
         }
         if (node == TRAV_DONE) {
             if (cur == NO_INST) break;
             cur = NO_INST; Oc = O; Dc = D; cull = flags; floor = 0;          // leave the instance
-            br = box_ray(O, D, sc.scale);
+            br = box_ray(O, D, sc.scale, sc.grid);
             if (sp > 0) { --sp; node = st.pop(sp); continue; }
             break;
         }
@@ -337,7 +371,7 @@ __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, floa
                 }
                 cull = f; cur = ii; floor = sp;
                 if (!in.identity) { Oc = xform_point(in.inv, O); Dc = xform_dir(in.inv, D); }
-                br = box_ray(Oc, Dc, in.scale);
+                br = box_ray(Oc, Dc, in.scale, in.grid);
                 node = (int)in.root;
             } else if (sp > 0) { --sp; node = st.pop(sp); } else node = TRAV_DONE;
         }

@@ -50,7 +50,8 @@ hipError_t launch_pack_tris(const void* verts, const uint32_t* idx, const BuildB
                             hipStream_t s);
 hipError_t launch_inst_setup(const InstDev* insts, const float* blas_bounds, uint32_t n, const BuildBuffers& b, hipStream_t s);
 // copy a BLAS into the scene pool: internal refs += node_off, leaf refs ~l -> ~(l + tri_off)
-hipError_t launch_rebase_nodes(BvhNode* dst, const BvhNode* src, uint32_t n_nodes, uint32_t node_off, uint32_t tri_off, hipStream_t s);
+hipError_t launch_quantize_nodes(QNode* dst, const BvhNode* src, uint32_t n_nodes, const QGrid& g, uint32_t node_off, uint32_t tri_off,
+                                 hipStream_t s);
 hipError_t launch_env_pad(const float* rgb, float4* out, uint32_t n_texels, hipStream_t s);
 
 } // namespace rr

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void k_render_async(SceneDev sc, DispatchDev a
 
     uint32_t n_rays = 0, n_hits = 0, n_miss = 0, n_term = 0, n_tir = 0, n_nodes = 0, n_tris = 0;
     uint32_t err = 0;
-    const float4* __restrict__ nodes = reinterpret_cast<const float4*>(sc.blas0.nodes);
+    const QNode* __restrict__ nodes = sc.blas0.nodes;
 
     // ---- per-lane state -------------------------------------------------------------------------
     bool alive = valid;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void k_render_async(SceneDev sc, DispatchDev a
     uint32_t count = 0;
     bool outside = true;
     float tmin = a.tmin_p;
-    BoxRay br = box_ray(O, D, sc.blas0.scale);
+    BoxRay br = box_ray(O, D, sc.blas0.scale, sc.blas0.grid);
     HitRec h;
     h.t = a.tmax_p; h.hit = false; h.prim = 0; h.leaf = 0; h.inst = 0; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f;
     int node = 0, sp = 0;
@@ -254,10 +254,9 @@ __global__ __launch_bounds__(256) void k_render_async(SceneDev sc, DispatchDev a
         if (nI >= nL && nI >= nS) {
             // ---- internal node step -----------------------------------------------------------------
             if (wantI) {
-                const float4* q = nodes + (uint32_t)node * 4u;
-                const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                const NodeQ q = load_node(nodes, node);
                 if (STATS) ++n_nodes;
-                node = node_step<true>(br, q0, q1, q2, q3, tmin, h.t, Stack32{ stk }, sp, 0, STACK, err);
+                node = node_step<true>(br, q, tmin, h.t, Stack32{ stk }, sp, 0, STACK, err);
             }
         } else if (nL >= nS) {
             // ---- triangle step ------------------------------------------------------------------------
@@ -324,7 +323,7 @@ __global__ __launch_bounds__(256) void k_render_async(SceneDev sc, DispatchDev a
                 }
                 if (have_next) {                                          // TraceRay(child, [1e-3, 1000])
                     tmin = a.tmin_s;
-                    br = box_ray(O, D, sc.blas0.scale);
+                    br = box_ray(O, D, sc.blas0.scale, sc.blas0.grid);
                     h.t = a.tmax_s; h.hit = false; h.prim = 0; h.leaf = 0; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f;
                     node = 0; sp = 0;
                 } else {                                                  // RenderTarget[xy] = float4(color,1)

@@ -1,7 +1,9 @@
 // rr_types.h -- records shared by the host side of the C ABI and the gfx950 kernels.
 //
 // HBM layout (all arrays 16-byte aligned, hipMalloc'ed once per mesh / scene):
-//   BvhNode  64 B  both child boxes + both child refs: ONE aligned half cache line per visit
+//   QNode    32 B  what traversal reads: both child boxes on the 16-bit grid of the BLAS bounds + both child
+//                  refs, TWO 16-byte requests per visit (the render kernel is bound by L1 request rate)
+//   BvhNode  64 B  the same node in fp32 (builder output, rr_download_blas); QNode is derived from it
 //   TriRec   48 B  v0,e1,e2 in LBVH leaf order, original PrimitiveIndex() in v0.w
 //   NrmRec   48 B  the three vertex normals of the same triangle (ClosestHit, RayTracing.hlsl:83-85)
 //   env      16 B  per texel (RGB32F padded to float4: one dwordx4 load per Miss)
@@ -22,6 +24,18 @@ struct alignas(16) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 B");
 
+// 16-bit grid over the bounds of one BLAS (object space) or of the scene (TLAS level): plane = org + q*cell.
+struct QGrid { float org[3]; float cell[3]; };
+// Traversal node.  Every word holds one slab plane of both children: child 0 in the low half, child 1 in the
+// high half, so two conversions feed one v_pk_fma_f32.  lo planes are rounded down, hi planes up (one extra
+// cell each way): the quantised box always contains the fp32 box, which is all the box test needs.
+struct alignas(16) QNode {
+    uint32_t lox, loy, loz, hix;
+    uint32_t hiy, hiz;
+    int32_t c[2];             // child refs, as in BvhNode
+};
+static_assert(sizeof(QNode) == 32, "QNode must be 32 B");
+
 struct alignas(16) TriRec {
     float v0[3]; uint32_t prim;
     float e1[3]; uint32_t pad1;
@@ -38,7 +52,8 @@ static_assert(sizeof(NrmRec) == 48, "NrmRec must be 48 B");
 
 // one BLAS as the traversal kernels see it
 struct BlasDev {
-    const BvhNode* nodes;
+    const QNode* nodes;
+    QGrid grid;
     const TriRec*  tris;
     const NrmRec*  nrms;
     uint32_t n_tris;
@@ -55,8 +70,10 @@ struct alignas(16) InstDev {
     uint32_t mask;
     uint32_t identity;
     float    scale;           // largest |coordinate| of the BLAS bounds (box-test padding in object space)
-    uint32_t pad[3];
+    QGrid    grid;            // of the BLAS this instance refers to
+    uint32_t pad;
 };
+static_assert(sizeof(InstDev) == 96, "InstDev must be 96 B");
 
 // Scenes beyond the reference's single identity instance are FLATTENED at rr_build_tlas: the TLAS nodes
 // and the nodes of every BLAS in use live in one node pool (child refs rebased), triangles and normals
@@ -64,7 +81,8 @@ struct alignas(16) InstDev {
 // otherwise, so one traversal loop walks both levels.
 struct SceneDev {
     BlasDev  blas0;           // used directly when the scene is one identity instance (the reference's case)
-    const BvhNode* pool_nodes;    // [0, n_insts-1): TLAS, then the BLASes
+    const QNode* pool_nodes;      // [0, n_insts-1): TLAS (on the scene grid), then the BLASes (each on its own grid)
+    QGrid grid;                   // scene grid (world space)
     const TriRec*  pool_tris;
     const NrmRec*  pool_nrms;
     const InstDev* insts;

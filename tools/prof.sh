@@ -5,13 +5,13 @@ tag=$1; shift
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-cpu-baseline "$@" > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-cpu-baseline --no-subdiv "$@" > $out/bench.log 2>&1
 echo "rc=$?" >> $out/bench.log
 find $out/trace -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $out/kernel_stats.csv
 rm -rf $out/trace
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE VALUBusy VALUUtilization"; do
   n=$(echo $c | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$n -- python3 bench.py --no-cpu-baseline "$@" > $out/pmc_$n.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$n -- python3 bench.py --no-cpu-baseline --no-subdiv "$@" > $out/pmc_$n.log 2>&1
   f=$(find $out/pmc_$n -name '*counter_collection.csv' | head -1)
   python3 - "$f" >> $out/pmc_summary.txt <<'PY'
 import csv, sys, collections
