@@ -465,7 +465,8 @@ __global__ __launch_bounds__(256) void k_quantize_nodes(QNode* __restrict__ dst,
     q.hix = q_hi(s.hix[0], g.org[0], g.cell[0]) | (q_hi(s.hix[1], g.org[0], g.cell[0]) << 16);
     q.hiy = q_hi(s.hiy[0], g.org[1], g.cell[1]) | (q_hi(s.hiy[1], g.org[1], g.cell[1]) << 16);
     q.hiz = q_hi(s.hiz[0], g.org[2], g.cell[2]) | (q_hi(s.hiz[1], g.org[2], g.cell[2]) << 16);
-    for (int k = 0; k < 2; ++k) q.c[k] = s.c[k] >= 0 ? s.c[k] + (int)node_off : ~(int)((uint32_t)~s.c[k] + tri_off);
+    // internal refs become BYTE offsets into the (pooled) QNode array; leaf refs stay ~index
+    for (int k = 0; k < 2; ++k) q.c[k] = s.c[k] >= 0 ? (int)(((uint32_t)s.c[k] + node_off) * (uint32_t)sizeof(QNode)) : ~(int)((uint32_t)~s.c[k] + tri_off);
     dst[i] = q;
 }
 

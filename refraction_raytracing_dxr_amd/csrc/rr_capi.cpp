@@ -432,6 +432,7 @@ int rr_build_blas_ex(rr_context* ctx, uint32_t mesh_id, uint32_t flags)
     if (mesh_id >= ctx->meshes.size()) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_build_blas: unknown mesh id");
     MeshRes& m = ctx->meshes[mesh_id];
     const uint32_t n = m.n_tris;
+    if ((uint64_t)n * sizeof(QNode) >= 0x7fffffffull) return fail(ctx, RR_ERR_UNSUPPORTED, "rr_build_blas: mesh too large for 31-bit node refs");
     BuildScratch s;
     if (int r = alloc_build(ctx, n, s)) return r;
     dfree(m.nodes); dfree(m.qnodes); dfree(m.tris); dfree(m.nrms);
@@ -484,7 +485,8 @@ int rr_build_tlas(rr_context* ctx, const rr_instance_desc* instances, uint32_t n
         n_pool_nodes += m.n_tris > 1 ? m.n_tris - 1 : 1;
         n_pool_tris += m.n_tris;
     }
-    if ((uint64_t)n_pool_tris + n >= 0x7fffffffull) return fail(ctx, RR_ERR_UNSUPPORTED, "rr_build_tlas: scene too large for 31-bit leaf refs");
+    if ((uint64_t)n_pool_tris + n >= 0x7fffffffull || (uint64_t)n_pool_nodes * sizeof(QNode) >= 0x7fffffffull)
+        return fail(ctx, RR_ERR_UNSUPPORTED, "rr_build_tlas: scene too large for 31-bit node / leaf refs");
     std::vector<InstDev> host(n);
     float scene_scale = 0.0f;
     std::vector<float> xb((size_t)n * 18);
@@ -500,7 +502,7 @@ int rr_build_tlas(rr_context* ctx, const rr_instance_desc* instances, uint32_t n
             for (int k = 0; k < 12; ++k)
                 if (!std::isfinite(o.inv[k])) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_build_tlas: singular instance transform");
         }
-        o.root = node_off[(size_t)d.blas];
+        o.root = node_off[(size_t)d.blas] * (uint32_t)sizeof(QNode);     // byte offset, like every internal child ref
         o.scale = m.scale;
         o.grid = m.grid;
         for (int c = 0; c < 8; ++c) {       // world-space extent of the instance (for the TLAS box padding)
@@ -721,7 +723,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         RR_HIP(hipEventRecord(ctx->kev[(size_t)ctx->kev_used * 2], ctx->stream));
     }
     int stack_sel = need <= 16 ? 16 : need <= 24 ? 24 : need <= 32 ? 32 : 64;
-    if (const char* ov = getenv("RR_DEBUG_STACK")) stack_sel = atoi(ov);   // experiments only
+    if (const char* ov = getenv("RR_DEBUG_STACK")) { const int v = atoi(ov); if (v >= (int)need) stack_sel = v; }   // experiments only; never below the tree depth (the kernels do not check)
     RR_HIP(launch_render_fused(sc, a, stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream));
     if (timed) {
         RR_HIP(hipEventRecord(ctx->kev[(size_t)ctx->kev_used * 2 + 1], ctx->stream));

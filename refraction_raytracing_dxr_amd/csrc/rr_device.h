@@ -154,9 +154,11 @@ __device__ __forceinline__ BoxRay box_ray(f3 O, f3 D, float scene_scale, const Q
 
 // a QNode as traversal loads it: two 16-byte requests
 struct NodeQ { uint4 a, b; };
+// node: an internal child ref = BYTE offset of the node inside the array (uniform base + 32-bit lane offset:
+// the address needs no VALU work)
 __device__ __forceinline__ NodeQ load_node(const QNode* __restrict__ nodes, int node)
 {
-    const uint4* q = reinterpret_cast<const uint4*>(nodes) + (uint32_t)node * 2u;
+    const uint4* q = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(nodes) + (uint32_t)node);
     NodeQ n;
     n.a = q[0]; n.b = q[1];
     return n;
@@ -199,24 +201,14 @@ __device__ __forceinline__ void box2_hit(const BoxRay& r, const NodeQ& n, float 
     h1 = tn1 <= tf1;
 }
 
-// per-lane traversal stack in LDS, column layout (entry e of lane l at base[e*64 + l]: conflict-free)
-struct Stack32 {
-    uint32_t* p;
-    __device__ __forceinline__ void push(int sp, int v) const { p[sp * 64] = (uint32_t)v; }
-    __device__ __forceinline__ int pop(int sp) const { return (int)p[sp * 64]; }
-};
-// 16-bit entries (half the LDS) for BVHs with < 32768 nodes and leaves: internal i -> i, leaf ~l -> 0x8000 | l
-struct Stack16 {
-    uint16_t* p;
-    __device__ __forceinline__ void push(int sp, int v) const { p[sp * 64] = v >= 0 ? (uint16_t)v : (uint16_t)(0x8000u | (uint32_t)~v); }
-    __device__ __forceinline__ int pop(int sp) const { const uint32_t u = p[sp * 64]; return (u & 0x8000u) ? ~(int)(u & 0x7fffu) : (int)u; }
-};
+// per-lane traversal stack in LDS, column layout (entry e of lane l at base[e*64 + l]: conflict-free).  The
+// stack pointer is the LDS address of the next free entry; depth never exceeds the tree depth (near child
+// followed, far child pushed), and the host picks a stack at least that deep, so there is no overflow check.
+constexpr int STACK_STRIDE = 64;
 
 // one traversal step at an internal node: returns the next node (near child, or a popped entry, or
-// TRAV_DONE) and pushes the far child when both are hit.  stk: this lane's LDS column, sp0: stack floor.
-template <bool CHECK, class StackT>
-__device__ __forceinline__ int node_step(const BoxRay& br, const NodeQ& n,
-                                         float tmin, float tmax, const StackT stk, int& sp, int sp0, int cap, uint32_t& err)
+// TRAV_DONE) and pushes the far child when both are hit.  top: next free entry, floor: lowest entry that may be popped.
+__device__ __forceinline__ int node_step(const BoxRay& br, const NodeQ& n, float tmin, float tmax, uint32_t*& top, const uint32_t* floor)
 {
     bool h0, h1;
     float tn0, tn1;
@@ -225,10 +217,8 @@ __device__ __forceinline__ int node_step(const BoxRay& br, const NodeQ& n,
     const bool both = h0 && h1, swap = tn1 < tn0;
     const int nearc = (h0 && !(h1 && swap)) ? c0 : c1;
     int next = (h0 || h1) ? nearc : TRAV_DONE;
-    if (both) {
-        if (!CHECK || sp < cap) { stk.push(sp, swap ? c0 : c1); ++sp; } else err = 1u;
-    }
-    if (!(h0 || h1) && sp > sp0) { --sp; next = stk.pop(sp); }
+    if (both) { *top = (uint32_t)(swap ? c0 : c1); top += STACK_STRIDE; }
+    if (!(h0 || h1) && top > floor) { top -= STACK_STRIDE; next = (int)*top; }
     return next;
 }
 
@@ -275,21 +265,20 @@ __device__ __forceinline__ void tri_test(const TriRec* __restrict__ tris, uint32
 // "while-while" form: all lanes first descend internal nodes (near child first, far child pushed)
 // until every lane of the wave holds a leaf or has finished; only then is the (expensive) triangle
 // test executed, once, for all lanes that hold a leaf.
-template <int STACK, bool STATS, class StackT = Stack32>
+template <bool STATS>
 __device__ __forceinline__ void trace_blas(const BlasDev& bl, f3 O, f3 D, float tmin, uint32_t cull, uint32_t inst,
-                                           HitRec& best, const StackT stk, int sp0, uint32_t* err, TravCounters& cnt,
-                                           const Diag dg = Diag{ nullptr })
+                                           HitRec& best, uint32_t* stk, TravCounters& cnt, const Diag dg = Diag{ nullptr })
 {
     const BoxRay br = box_ray(O, D, bl.scale, bl.grid);
     const QNode* __restrict__ nodes = bl.nodes;
-    int sp = sp0;
+    uint32_t* top = stk;
     int node = 0;
     for (;;) {
         while (node >= 0) {
             diag_trip(dg);
             const NodeQ q = load_node(nodes, node);
             if (STATS) cnt.nodes++;
-            node = node_step<true>(br, q, tmin, best.t, stk, sp, sp0, STACK, *err);
+            node = node_step(br, q, tmin, best.t, top, stk);
 #ifdef RR_EXP_EXTRA_VALU      // experiment: what do N more VALU instructions per visit cost?
             { float dv = br.inv.x;
 #pragma unroll
@@ -301,7 +290,7 @@ __device__ __forceinline__ void trace_blas(const BlasDev& bl, f3 O, f3 D, float 
         diag_trip(dg, 1);
         if (STATS) cnt.tris++;
         tri_test(bl.tris, (uint32_t)~node, O, D, tmin, cull, inst, best);
-        if (sp > sp0) { --sp; node = stk.pop(sp); } else node = TRAV_DONE;
+        if (top > stk) { top -= STACK_STRIDE; node = (int)*top; } else node = TRAV_DONE;
     }
 }
 
@@ -322,43 +311,43 @@ __device__ __forceinline__ f3 xform_dir(const float* m, f3 p)
 // TLAS = false: the reference's scene, one BLAS.  TLAS = true: one loop over the flattened node pool;
 // reaching an instance leaf swaps the lane's ray for its object-space image (t is preserved: the
 // direction is not renormalised) and remembers the stack level, exhausting that level swaps it back.
-template <int STACK, bool STATS, bool TLAS>
+template <bool STATS, bool TLAS>
 __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, float tmin, float tmax, uint32_t flags,
-                                            HitRec& best, uint32_t* stk, uint32_t* err, TravCounters& cnt,
+                                            HitRec& best, uint32_t* stk, TravCounters& cnt,
                                             const Diag dg = Diag{ nullptr })
 {
     best.t = tmax; best.hit = false; best.prim = 0; best.leaf = 0; best.inst = 0; best.U = 0.0f; best.V = 0.0f;
     best.ad = 1.0f;
     if (!TLAS) {      // the reference's scene: one identity instance, mask 1, flags 0 (RefractionDemo.cpp:324-334)
-        trace_blas<STACK, STATS>(sc.blas0, O, D, tmin, flags, 0u, best, Stack32{ stk }, 0, err, cnt, dg);
+        trace_blas<STATS>(sc.blas0, O, D, tmin, flags, 0u, best, stk, cnt, dg);
         return;
     }
     const QNode* __restrict__ nodes = sc.pool_nodes;
-    const Stack32 st{ stk };
     constexpr uint32_t NO_INST = 0xffffffffu;
     BoxRay br = box_ray(O, D, sc.scale, sc.grid);
     f3 Oc = O, Dc = D;                      // the ray in the space of the level being walked
     uint32_t cull = flags, cur = NO_INST;
-    int sp = 0, floor = 0, node = 0;        // floor: stack level at which the current instance was entered
-    uint32_t e = 0;
+    uint32_t* top = stk;
+    const uint32_t* floor = stk;            // floor: stack level at which the current instance was entered
+    int node = 0;
     for (;;) {
         while (node >= 0) {
             const NodeQ q = load_node(nodes, node);
             if (STATS) cnt.nodes++;
-            node = node_step<true>(br, q, tmin, best.t, st, sp, floor, STACK, e);
+            node = node_step(br, q, tmin, best.t, top, floor);
         }
         if (node == TRAV_DONE) {
             if (cur == NO_INST) break;
-            cur = NO_INST; Oc = O; Dc = D; cull = flags; floor = 0;          // leave the instance
+            cur = NO_INST; Oc = O; Dc = D; cull = flags; floor = stk;        // leave the instance
             br = box_ray(O, D, sc.scale, sc.grid);
-            if (sp > 0) { --sp; node = st.pop(sp); continue; }
+            if (top > stk) { top -= STACK_STRIDE; node = (int)*top; continue; }
             break;
         }
         const uint32_t L = (uint32_t)~node;
         if (L < sc.n_pool_tris) {
             if (STATS) cnt.tris++;
             tri_test(sc.pool_tris, L, Oc, Dc, tmin, cull, cur, best);
-            if (sp > floor) { --sp; node = st.pop(sp); } else node = TRAV_DONE;
+            if (top > floor) { top -= STACK_STRIDE; node = (int)*top; } else node = TRAV_DONE;
         } else {
             const uint32_t ii = L - sc.n_pool_tris;
             const InstDev& in = sc.insts[ii];
@@ -369,14 +358,13 @@ __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, floa
                     if (f & CULL_BACK) f = (f & ~CULL_BACK) | CULL_FRONT;
                     else if (f & CULL_FRONT) f = (f & ~CULL_FRONT) | CULL_BACK;
                 }
-                cull = f; cur = ii; floor = sp;
+                cull = f; cur = ii; floor = top;
                 if (!in.identity) { Oc = xform_point(in.inv, O); Dc = xform_dir(in.inv, D); }
                 br = box_ray(Oc, Dc, in.scale, in.grid);
                 node = (int)in.root;
-            } else if (sp > 0) { --sp; node = st.pop(sp); } else node = TRAV_DONE;
+            } else if (top > stk) { top -= STACK_STRIDE; node = (int)*top; } else node = TRAV_DONE;
         }
     }
-    if (e) *err = 1u;
 }
 
 // ---- Miss: RayTracing.hlsl:127-137 -------------------------------------------------------------

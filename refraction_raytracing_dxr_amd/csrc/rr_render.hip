@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, TLAS ? RR_TLAS_WAVES_PER_SIMD : RR_FUSED_WAVES
         float tmin = a.tmin_p, tmax = a.tmax_p;
         for (;;) {
             HitRec h;
-            trace_scene<STACK, STATS, TLAS>(sc, O, D, tmin, tmax, outside ? CULL_BACK : CULL_FRONT, h, stk, &err, cnt,
+            trace_scene<STATS, TLAS>(sc, O, D, tmin, tmax, outside ? CULL_BACK : CULL_FRONT, h, stk, cnt,
                                             Diag{ DIAG ? &diag_trips[threadIdx.x >> 6] : nullptr });
             ++n_rays;
             if (DIAG) diag_trip(Diag{ &diag_trips[threadIdx.x >> 6] }, 2);
@@ -241,7 +241,8 @@ __global__ __launch_bounds__(256) void k_render_async(SceneDev sc, DispatchDev a
     BoxRay br = box_ray(O, D, sc.blas0.scale, sc.blas0.grid);
     HitRec h;
     h.t = a.tmax_p; h.hit = false; h.prim = 0; h.leaf = 0; h.inst = 0; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f;
-    int node = 0, sp = 0;
+    int node = 0;
+    uint32_t* top = stk;
 
     for (;;) {
         const bool wantI = alive && node >= 0;
@@ -256,14 +257,14 @@ __global__ __launch_bounds__(256) void k_render_async(SceneDev sc, DispatchDev a
             if (wantI) {
                 const NodeQ q = load_node(nodes, node);
                 if (STATS) ++n_nodes;
-                node = node_step<true>(br, q, tmin, h.t, Stack32{ stk }, sp, 0, STACK, err);
+                node = node_step(br, q, tmin, h.t, top, stk);
             }
         } else if (nL >= nS) {
             // ---- triangle step ------------------------------------------------------------------------
             if (wantL) {
                 if (STATS) ++n_tris;
                 tri_test(sc.blas0.tris, (uint32_t)~node, O, D, tmin, outside ? CULL_BACK : CULL_FRONT, 0u, h);
-                if (sp > 0) { --sp; node = (int)stk[sp * 64]; } else node = TRAV_DONE;
+                if (top > stk) { top -= STACK_STRIDE; node = (int)*top; } else node = TRAV_DONE;
             }
         } else {
             // ---- shading step: Miss / ClosestHit for every lane whose ray is finished -------------------
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256) void k_render_async(SceneDev sc, DispatchDev a
                     tmin = a.tmin_s;
                     br = box_ray(O, D, sc.blas0.scale, sc.blas0.grid);
                     h.t = a.tmax_s; h.hit = false; h.prim = 0; h.leaf = 0; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f;
-                    node = 0; sp = 0;
+                    node = 0; top = stk;
                 } else {                                                  // RenderTarget[xy] = float4(color,1)
                     const uint32_t packed = unorm8(acc.x) | (unorm8(acc.y) << 8) | (unorm8(acc.z) << 16) | 0xff000000u;
                     const size_t o = a.compact_out == 0u ? (size_t)y * a.W + x
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(256) void k_trace_rays(SceneDev sc, const rr_ray_de
     HitRec h;
     TravCounters cnt; cnt.nodes = 0; cnt.tris = 0;
     uint32_t err = 0;
-    trace_scene<STACK, false, TLAS>(sc, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), o.w, d.w, flags, h, stk, &err, cnt);
+    trace_scene<false, TLAS>(sc, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), o.w, d.w, flags, h, stk, cnt);
     rr_hit_dev r;
     r.hit = h.hit ? 1u : 0u;
     r.t = h.hit ? h.t : d.w;

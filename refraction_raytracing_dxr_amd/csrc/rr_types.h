@@ -32,7 +32,7 @@ struct QGrid { float org[3]; float cell[3]; };
 struct alignas(16) QNode {
     uint32_t lox, loy, loz, hix;
     uint32_t hiy, hiz;
-    int32_t c[2];             // child refs, as in BvhNode
+    int32_t c[2];             // child refs: >= 0 BYTE offset of an internal node in this array, < 0 leaf ~index
 };
 static_assert(sizeof(QNode) == 32, "QNode must be 32 B");
 
@@ -65,7 +65,7 @@ struct BlasDev {
 // instance record for two-level traversal (derived from the 64-byte rr_instance_desc)
 struct alignas(16) InstDev {
     float inv[12];            // world -> object 3x4
-    uint32_t root;            // root node of this instance's BLAS inside the scene pool
+    uint32_t root;            // byte offset of the root node of this instance's BLAS inside the scene pool
     uint32_t flags;           // RR_INSTANCE_FLAG_*
     uint32_t mask;
     uint32_t identity;
