@@ -243,6 +243,12 @@ int  rr_trace_rays(rr_context* ctx, const rr_ray* rays, uint32_t n, rr_hit* hits
 int  rr_download_blas(rr_context* ctx, uint32_t mesh_id, void* nodes, uint32_t* n_nodes,
                       void* tris, uint32_t* n_tris);
 
+/* The same hierarchy as the traversal kernels read it: n_nodes*32 B, per node six words holding one slab plane
+ * of both children on the BLAS's 16-bit grid (child 0 in the low half, child 1 in the high half; order
+ * lox,loy,loz,hix,hiy,hiz), then the two child refs (>= 0: byte offset of an internal node, < 0: leaf ~index).
+ * grid_org_cell: origin xyz then cell size xyz (plane = org + q*cell).  Every quantised box contains its fp32 box. */
+int  rr_download_qnodes(rr_context* ctx, uint32_t mesh_id, void* qnodes, uint32_t* n_nodes, float grid_org_cell[6]);
+
 /* ---- pure host helpers (no device, no context) --------------------------------------------- */
 void rr_default_dispatch_params(rr_dispatch_params* p);
 /* RefractionDemo.cpp:559-566: camera constants for an orbit angle.  The reference's literals are

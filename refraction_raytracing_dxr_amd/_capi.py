@@ -34,6 +34,9 @@ NODE_DTYPE = np.dtype([("lox", "<f4", 2), ("loy", "<f4", 2), ("loz", "<f4", 2), 
 TRI_DTYPE = np.dtype([("v0", "<f4", 3), ("prim", "<u4"), ("e1", "<f4", 3), ("pad1", "<u4"),
                       ("e2", "<f4", 3), ("pad2", "<u4")])
 assert VERTEX_DTYPE.itemsize == 32 and INSTANCE_DTYPE.itemsize == 64 and RAY_DTYPE.itemsize == 48
+QNODE_DTYPE = np.dtype([("lox", "<u2", 2), ("loy", "<u2", 2), ("loz", "<u2", 2), ("hix", "<u2", 2),
+                        ("hiy", "<u2", 2), ("hiz", "<u2", 2), ("c", "<i4", 2)])
+assert QNODE_DTYPE.itemsize == 32
 assert HIT_DTYPE.itemsize == 24 and NODE_DTYPE.itemsize == 64 and TRI_DTYPE.itemsize == 48
 
 
@@ -97,6 +100,7 @@ SYMBOLS = {
     "rr_kernel_time": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "rr_trace_rays": (C.c_int, [_P, _P, C.c_uint32, _P]),
     "rr_download_blas": (C.c_int, [_P, C.c_uint32, _P, C.POINTER(C.c_uint32), _P, C.POINTER(C.c_uint32)]),
+    "rr_download_qnodes": (C.c_int, [_P, C.c_uint32, _P, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
     "rr_default_dispatch_params": (None, [C.POINTER(DispatchParams)]),
     "rr_host_camera_orbit": (C.c_int, [C.c_float] * 5 + [C.POINTER(SceneConstants)]),
     "rr_host_mesh_load_obj": (C.c_int, [C.c_char_p, C.POINTER(_P), C.POINTER(C.c_uint32), C.POINTER(_P),

@@ -1098,4 +1098,18 @@ int rr_download_blas(rr_context* ctx, uint32_t mesh_id, void* nodes, uint32_t* n
     return RR_OK;
 }
 
+int rr_download_qnodes(rr_context* ctx, uint32_t mesh_id, void* qnodes, uint32_t* n_nodes, float grid_org_cell[6])
+{
+    if (int r = use_device(ctx)) return r;
+    if (mesh_id >= ctx->meshes.size()) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_download_qnodes: unknown mesh id");
+    const MeshRes& m = ctx->meshes[mesh_id];
+    if (!m.built) return fail(ctx, RR_ERR_STATE, "rr_download_qnodes: BLAS not built");
+    const uint32_t nn = m.n_tris > 1 ? m.n_tris - 1 : 1;
+    if (n_nodes) *n_nodes = nn;
+    if (grid_org_cell) { memcpy(grid_org_cell, m.grid.org, 12); memcpy(grid_org_cell + 3, m.grid.cell, 12); }
+    RR_HIP(hipStreamSynchronize(ctx->stream));
+    if (qnodes) RR_HIP(hipMemcpy(qnodes, m.qnodes, (size_t)nn * sizeof(QNode), hipMemcpyDeviceToHost));
+    return RR_OK;
+}
+
 } // extern "C"

@@ -297,6 +297,17 @@ class Renderer:
                                           C.byref(nt)), "rr_download_blas")
         return nodes, tris
 
+    def download_qnodes(self, mesh_id):
+        """-> (QNODE_DTYPE array, grid origin float32[3], grid cell float32[3]): the nodes as traversal reads them"""
+        from ._capi import QNODE_DTYPE
+        nn = C.c_uint32()
+        g = (C.c_float * 6)()
+        self._ck(self._L.rr_download_qnodes(self._h, mesh_id, None, C.byref(nn), g), "rr_download_qnodes")
+        q = np.zeros(nn.value, QNODE_DTYPE)
+        self._ck(self._L.rr_download_qnodes(self._h, mesh_id, q.ctypes.data, C.byref(nn), g), "rr_download_qnodes")
+        ga = np.array(list(g), np.float32)
+        return q, ga[:3], ga[3:]
+
     # convenience: the reference's whole init sequence for one mesh + env map
     def load_scene(self, verts, indices, env_rgb, instances=None):
         mid = self.upload_mesh(verts, indices)

@@ -141,6 +141,32 @@ def test_trace_rays_bit_exact_vs_brute_force(gpu, name, n):
     assert n_hit > n // 20
 
 
+@pytest.mark.parametrize("name", ["cube.obj", "monkey.obj", "ott.obj"])
+def test_quantised_nodes_contain_the_fp32_boxes(gpu, name):
+    """Traversal reads 32-byte nodes on a 16-bit grid of the mesh bounds.  The box test only has to be conservative:
+    every quantised child box must contain its fp32 box (evaluated in float64 from the same float32 grid the
+    kernels use), by at most three cells; child refs are the same tree with internal refs as byte offsets."""
+    m = load(name)
+    mid = gpu.upload_mesh(m.verts, m.indices)
+    gpu.build_blas(mid)
+    nodes, _ = gpu.download_blas(mid)
+    q, org, cell = gpu.download_qnodes(mid)
+    assert len(q) == len(nodes) and np.all(cell > 0)
+    org, cell = org.astype(np.float64), cell.astype(np.float64)
+    for ax, (lo, hi) in enumerate((("lox", "hix"), ("loy", "hiy"), ("loz", "hiz"))):
+        qlo = org[ax] + q[lo].astype(np.float64) * cell[ax]
+        qhi = org[ax] + q[hi].astype(np.float64) * cell[ax]
+        flo, fhi = nodes[lo].astype(np.float64), nodes[hi].astype(np.float64)
+        real = flo <= fhi                                      # (a one-triangle mesh has an empty second child)
+        assert np.all(qlo[real] <= flo[real]) and np.all(qhi[real] >= fhi[real])
+        assert np.all(flo[real] - qlo[real] <= 3 * cell[ax]) and np.all(qhi[real] - fhi[real] <= 3 * cell[ax])
+    c, qc = nodes["c"], q["c"]
+    assert np.array_equal(qc[c < 0], c[c < 0]) and np.array_equal(qc[c >= 0], c[c >= 0] * 32)
+    # the grid spans the mesh bounds
+    P = m.verts["position"][m.indices].astype(np.float64)
+    assert np.all(org <= P.min(0)) and np.all(org + 65535 * cell >= P.max(0))
+
+
 def test_fast_build_and_fast_trace_hierarchies_render_the_same_frame(gpu):
     m = load("monkey.obj")
     env = procedural_env(128, 64, seed=31)
