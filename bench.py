@@ -173,12 +173,17 @@ def main():
     subdiv = None
     if rank == 0:
         r.set_tile_partition(0, 1)
-        n_prof = max(F, (min(K, 256) // F) * F)                              # whole launches of F slices
-        r.render_orbit(W, H, n_prof, angle=0.01, frames_per_dispatch=F, params=rr.default_params(
-            max_refract=MAX_REFRACT, max_reflect=MAX_REFLECT, flags=rr.DISPATCH_COLLECT_STATS))
-        sst = r.stats()                                                     # exact counters, summed over n_prof frames
-        r.render_orbit(W, H, n_prof, angle=0.01, frames_per_dispatch=F, params=rr.default_params(
-            max_refract=MAX_REFRACT, max_reflect=MAX_REFLECT, flags=rr.DISPATCH_TIME_KERNEL))
+        # whole launches of F consecutive frames, their start angles spread over the timed orbit (consecutive frames
+        # share cache lines, so a launch must hold consecutive frames to be a launch of the timed loop)
+        n_launch = max(1, min(K, 512) // F)
+        n_prof = n_launch * F
+        starts = [0.01 + 0.01 * ((K // n_launch) * j) for j in range(n_launch)]
+        for flag in (rr.DISPATCH_COLLECT_STATS, rr.DISPATCH_TIME_KERNEL):
+            for j, a0 in enumerate(starts):
+                r.render_orbit(W, H, F, angle=a0, frames_per_dispatch=F, params=rr.default_params(
+                    max_refract=MAX_REFRACT, max_reflect=MAX_REFLECT, flags=flag | (rr.DISPATCH_KEEP_COUNTERS if j else 0)))
+            if flag == rr.DISPATCH_COLLECT_STATS:
+                sst = r.stats()                                             # exact counters, summed over n_prof frames
         kms, kn = r.kernel_time()                                           # HIP events around each launch, on the launch stream
         bytes_per_launch = algorithmic_bytes(sst) / kn                      # one launch = F frames
         kernel_us = kms / kn * 1e3
