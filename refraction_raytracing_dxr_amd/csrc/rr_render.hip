@@ -15,9 +15,12 @@
 #include "rr_device.h"
 #include "rr_launch.h"
 
-// minimum waves per SIMD the register allocator must leave room for (96 VGPRs; measured +6..8 % over 4)
+// minimum waves per SIMD the register allocator must leave room for.  Measured (Depth 64, us/frame): 4 waves
+// 123 / 214 / 180 on monkey / sphere / ott, 5 waves (96 VGPRs, no spill) 108 / 189 / 178, 6 waves (80 VGPRs,
+// 15 words spilled) 104 / 183 / 186.  A 32-entry stack (ott.obj) caps the CU at 5 workgroups anyway (LDS), so
+// only the shallow-tree instantiations ask for 6.
 #ifndef RR_FUSED_WAVES_PER_SIMD
-#define RR_FUSED_WAVES_PER_SIMD 5
+#define RR_FUSED_WAVES_PER_SIMD(STACK) ((STACK) <= 24 ? 6 : 5)
 #endif
 #ifndef RR_TLAS_WAVES_PER_SIMD
 #define RR_TLAS_WAVES_PER_SIMD 4
@@ -50,7 +53,7 @@ __device__ __forceinline__ void block_to_tile(uint32_t b, uint32_t& tile_local, 
 }
 
 template <int STACK, int PEND, bool STATS, bool TLAS, bool DIAG = false>
-__global__ __launch_bounds__(256, TLAS ? RR_TLAS_WAVES_PER_SIMD : RR_FUSED_WAVES_PER_SIMD) void k_render_fused(SceneDev sc, DispatchDev a)
+__global__ __launch_bounds__(256, TLAS ? RR_TLAS_WAVES_PER_SIMD : RR_FUSED_WAVES_PER_SIMD(STACK)) void k_render_fused(SceneDev sc, DispatchDev a)
 {
     __shared__ uint32_t diag_trips[12];    // per wave: internal trips, leaf trips, shading passes
     const unsigned long long diag_t0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -244,29 +247,37 @@ __global__ __launch_bounds__(256) void k_render_async(SceneDev sc, DispatchDev a
     int node = 0;
     uint32_t* top = stk;
 
+#ifndef RR_SHADE_SHIFT
+#define RR_SHADE_SHIFT 1
+#endif
     for (;;) {
-        const bool wantI = alive && node >= 0;
-        const bool wantL = alive && node < 0 && node != TRAV_DONE;
-        const bool wantS = alive && node == TRAV_DONE;
-        const unsigned long long mI = __ballot(wantI), mL = __ballot(wantL), mS = __ballot(wantS);
-        if ((mI | mL | mS) == 0ull) break;
-        const int nI = __popcll(mI), nL = __popcll(mL), nS = __popcll(mS);
-        if (DIAG) { ++diag_trips; if (nI >= nL && nI >= nS) ++diag_tI; else if (nL >= nS) ++diag_tL; else ++diag_tS; }
-        if (nI >= nL && nI >= nS) {
-            // ---- internal node step -----------------------------------------------------------------
-            if (wantI) {
+        // ---- travel: lanes whose ray is not finished.  The phase ends for the wave once 1/2^RR_SHADE_SHIFT of
+        // them are waiting to be shaded (scalar count of exec, as in trace_blas).
+        const int n_trav = __popcll(__ballot(alive && node != TRAV_DONE));
+        while (alive && node != TRAV_DONE) {
+            {
+                const int part = n_trav >> RR_SHADE_SHIFT;
+                if (__popcll(__ballot(1)) + (part > 1 ? part : 1) <= n_trav) break;
+            }
+            if (DIAG) ++diag_trips;
+            const int n_in = __popcll(__ballot(node >= 0));
+            while (node >= 0) {
+                if (leaf_phase_due(n_in)) break;
+                if (DIAG) ++diag_tI;
                 const NodeQ q = load_node(nodes, node);
                 if (STATS) ++n_nodes;
                 node = node_step(br, q, tmin, h.t, top, stk);
             }
-        } else if (nL >= nS) {
-            // ---- triangle step ------------------------------------------------------------------------
-            if (wantL) {
+            if (node < 0 && node != TRAV_DONE) {
+                if (DIAG) ++diag_tL;
                 if (STATS) ++n_tris;
                 tri_test(sc.blas0.tris, (uint32_t)~node, O, D, tmin, outside ? CULL_BACK : CULL_FRONT, 0u, h);
                 if (top > stk) { top -= STACK_STRIDE; node = (int)*top; } else node = TRAV_DONE;
             }
-        } else {
+        }
+        {
+            const bool wantS = alive && node == TRAV_DONE;
+            if (DIAG && __ballot(wantS)) ++diag_tS;
             // ---- shading step: Miss / ClosestHit for every lane whose ray is finished -------------------
             if (wantS) {
                 ++n_rays;
@@ -337,6 +348,7 @@ __global__ __launch_bounds__(256) void k_render_async(SceneDev sc, DispatchDev a
                 }
             }
         }
+        if (__ballot(alive) == 0ull) break;
     }
 
     if (DIAG) {
