@@ -79,6 +79,8 @@ typedef struct rr_dispatch_params {
 #define RR_DISPATCH_COLLECT_STATS 0x2u  /* instrumented kernel: node/triangle/hit/miss counters */
 #define RR_DISPATCH_TIME_KERNEL   0x4u  /* bracket the render kernel with a HIP event pair (rr_kernel_time) */
 #define RR_DISPATCH_KEEP_COUNTERS 0x8u  /* do not zero the rr_get_stats counters first: keep accumulating */
+#define RR_DISPATCH_TILES_RGB8    0x10u /* rr_render_orbit_sharded only: tiles are written as 3 bytes per pixel (alpha is
+                                         * always 255): a quarter less to gather; rr_assemble_frames_rgb8 restores RGBA8 */
 
 typedef struct rr_stats {
     uint64_t rays;                /* every TraceRay: primary + secondary */
@@ -88,7 +90,7 @@ typedef struct rr_stats {
     uint64_t misses;
     uint64_t terminal_hits;       /* ClosestHit with count >= max_refract */
     uint64_t tir;                 /* RefractRay returned false */
-    uint64_t node_visits;         /* internal BVH nodes fetched (64 B each)  */
+    uint64_t node_visits;         /* internal BVH nodes fetched (32 B each)  */
     uint64_t tri_tests;           /* triangle records fetched (48 B each)    */
     uint64_t pixels;              /* pixels this context rendered (last dispatch, or all frames of rr_render_orbit) */
     uint32_t stats_valid;         /* 1 if the last dispatch ran with RR_DISPATCH_COLLECT_STATS */
@@ -222,6 +224,10 @@ int  rr_lane_join(rr_context* ctx, uint32_t lane);
 int  rr_assemble_frames(rr_context* ctx, const void* d_gathered, uint32_t world, uint64_t rank_stride_bytes,
                         uint64_t frame_stride_bytes, uint32_t n_frames, uint32_t width, uint32_t height,
                         void* d_frames, uint64_t out_stride_bytes);
+/* The same for tiles rendered with RR_DISPATCH_TILES_RGB8 (max_tiles_any_rank*3072 B per frame and rank); output RGBA8. */
+int  rr_assemble_frames_rgb8(rr_context* ctx, const void* d_gathered, uint32_t world, uint64_t rank_stride_bytes,
+                             uint64_t frame_stride_bytes, uint32_t n_frames, uint32_t width, uint32_t height,
+                             void* d_frames, uint64_t out_stride_bytes);
 
 /* HIP-event timing on the stream the kernels run on.  rr_timing_begin records an event,
  * rr_timing_end records another, waits for it and returns the elapsed milliseconds. */

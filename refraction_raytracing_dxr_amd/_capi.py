@@ -15,6 +15,7 @@ DISPATCH_FLOAT_OUTPUT = 0x1
 DISPATCH_COLLECT_STATS = 0x2
 DISPATCH_TIME_KERNEL = 0x4
 DISPATCH_KEEP_COUNTERS = 0x8
+DISPATCH_TILES_RGB8 = 0x10
 BUILD_PREFER_FAST_TRACE = 0x4
 BUILD_PREFER_FAST_BUILD = 0x8
 RAY_FLAG_CULL_BACK = 0x10
@@ -95,6 +96,8 @@ SYMBOLS = {
     "rr_set_frames_in_flight": (C.c_int, [_P, C.c_uint32]),
     "rr_assemble_frames": (C.c_int, [_P, _P, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                      _P, C.c_uint64]),
+    "rr_assemble_frames_rgb8": (C.c_int, [_P, _P, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          _P, C.c_uint64]),
     "rr_timing_begin": (C.c_int, [_P]),
     "rr_timing_end": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "rr_kernel_time": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),

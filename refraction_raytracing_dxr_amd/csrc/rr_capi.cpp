@@ -671,7 +671,10 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     tile_counts(width, height, ctx->tile_rank, ctx->tile_world, tiles_x, n_tiles, local, max_local);
     const bool want_f32 = (p.flags & RR_DISPATCH_FLOAT_OUTPUT) != 0;
     const bool compact = ctx->tile_world > 1 || ext_tiles != nullptr;
-    const size_t slice_elems = compact ? (size_t)max_local * TILE * TILE : (size_t)width * height;
+    const bool rgb8 = (p.flags & RR_DISPATCH_TILES_RGB8) != 0;
+    if (rgb8 && !ext_tiles) return fail(ctx, RR_ERR_UNSUPPORTED, "dispatch: RGB8 tiles only exist in external tile buffers (rr_render_orbit_sharded)");
+    // elements are 32-bit words; an RGB8 tile is 3/4 of an RGBA8 tile
+    const size_t slice_elems = compact ? (size_t)max_local * TILE * TILE * (rgb8 ? 3 : 4) / 4 : (size_t)width * height;
     const size_t stride = ext_tiles ? ext_stride_elems : slice_elems;
     if (ext_tiles && want_f32) return fail(ctx, RR_ERR_UNSUPPORTED, "dispatch: float output is not available for external tile buffers");
     const size_t out_base = ext_tiles ? 0 : slice_elems * out_slot_depth * out_slot;
@@ -690,7 +693,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     a.tile_rank = ctx->tile_rank; a.tile_world = ctx->tile_world;
     a.n_local_tiles = local;
     a.n_blocks = a.blocks_per_frame * depth;
-    a.compact_out = compact ? 1u : 0u;
+    a.compact_out = compact ? (rgb8 ? 2u : 1u) : 0u;
     a.max_refract = p.max_refract; a.max_reflect = p.max_reflect;
     a.ior = p.ior; a.inv_ior = 1.0f / p.ior;
     a.tmin_p = p.tmin_primary; a.tmax_p = p.tmax_primary; a.tmin_s = p.tmin_secondary; a.tmax_s = p.tmax_secondary;
@@ -710,8 +713,8 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     if (!keep) RR_HIP(hipMemsetAsync(ctx->d_cnt, 0, sizeof(CounterBlock), ctx->stream));
     if (compact && local < max_local)            // keep the gathered tail deterministic
         for (uint32_t f = 0; f < depth; ++f)
-            RR_HIP(hipMemsetAsync(a.out_rgba8 + f * stride + (size_t)local * TILE * TILE, 0,
-                                  (size_t)(max_local - local) * TILE * TILE * 4, ctx->stream));
+            RR_HIP(hipMemsetAsync(reinterpret_cast<uint8_t*>(a.out_rgba8 + f * stride) + (size_t)local * TILE * TILE * (rgb8 ? 3 : 4), 0,
+                                  (size_t)(max_local - local) * TILE * TILE * (rgb8 ? 3 : 4), ctx->stream));
     const bool timed = (p.flags & RR_DISPATCH_TIME_KERNEL) != 0;
     if (timed) {
         if (ctx->kev_used >= 4096) return fail(ctx, RR_ERR_STATE, "dispatch: 4096 timed dispatches pending, call rr_kernel_time");
@@ -931,7 +934,8 @@ int rr_render_orbit_sharded(rr_context* ctx, uint32_t width, uint32_t height, co
     if (!d_tiles) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_render_orbit_sharded: null tile buffer");
     uint32_t tx, nt, local, mx;
     tile_counts(width ? width : 1, height ? height : 1, ctx->tile_rank, ctx->tile_world, tx, nt, local, mx);
-    if (frame_stride_bytes < (uint64_t)mx * TILE * TILE * 4 || (frame_stride_bytes & 3u))
+    const uint64_t bpp = (params && (params->flags & RR_DISPATCH_TILES_RGB8)) ? 3 : 4;
+    if (frame_stride_bytes < (uint64_t)mx * TILE * TILE * bpp || (frame_stride_bytes & 3u))
         return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_render_orbit_sharded: frame stride smaller than a tile buffer");
     return orbit_impl(ctx, width, height, params, angle, angle_step, n_frames, frames_per_dispatch, fov_y, aspect, zn, zf,
                       (uint32_t*)d_tiles, (size_t)(frame_stride_bytes / 4));
@@ -990,6 +994,22 @@ int rr_assemble_frames(rr_context* ctx, const void* d_gathered, uint32_t world, 
         return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_assemble_frames: stride too small");
     RR_HIP(launch_assemble_frames((const uint32_t*)d_gathered, (uint32_t*)d_frames, width, height, tx, nt, world,
                                   rank_stride_bytes / 4, frame_stride_bytes / 4, out_stride_bytes / 4, n_frames, ctx->stream));
+    return RR_OK;
+}
+
+int rr_assemble_frames_rgb8(rr_context* ctx, const void* d_gathered, uint32_t world, uint64_t rank_stride_bytes,
+                            uint64_t frame_stride_bytes, uint32_t n_frames, uint32_t width, uint32_t height, void* d_frames,
+                            uint64_t out_stride_bytes)
+{
+    if (int r = use_device(ctx)) return r;
+    if (!d_gathered || !d_frames || world == 0 || width == 0 || height == 0 || (out_stride_bytes & 3u))
+        return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_assemble_frames_rgb8: bad arguments");
+    uint32_t tx, nt, local, mx;
+    tile_counts(width, height, 0, world, tx, nt, local, mx);
+    if (frame_stride_bytes < (uint64_t)mx * TILE * TILE * 3 || out_stride_bytes < (uint64_t)width * height * 4)
+        return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_assemble_frames_rgb8: stride too small");
+    RR_HIP(launch_assemble_frames_rgb8((const uint8_t*)d_gathered, (uint32_t*)d_frames, width, height, tx, nt, world,
+                                       rank_stride_bytes, frame_stride_bytes, out_stride_bytes / 4, n_frames, ctx->stream));
     return RR_OK;
 }
 

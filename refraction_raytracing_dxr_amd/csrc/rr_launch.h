@@ -20,6 +20,9 @@ hipError_t launch_assemble_tiles(const uint32_t* gathered, uint32_t* frame, uint
 hipError_t launch_assemble_frames(const uint32_t* gathered, uint32_t* frames, uint32_t W, uint32_t H, uint32_t tiles_x,
                                   uint32_t n_tiles, uint32_t world, size_t rank_stride, size_t frame_stride,
                                   size_t out_stride, uint32_t n_frames, hipStream_t s);
+hipError_t launch_assemble_frames_rgb8(const uint8_t* gathered, uint32_t* frames, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles,
+                                       uint32_t world, size_t rank_stride_b, size_t frame_stride_b, size_t out_stride, uint32_t n_frames,
+                                       hipStream_t s);
 
 // ---- rr_bvh_build.hip
 // Scratch + outputs of one LBVH build over n primitives (triangles of a mesh, or instances).

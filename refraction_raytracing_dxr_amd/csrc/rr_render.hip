@@ -160,7 +160,12 @@ __global__ __launch_bounds__(256, TLAS ? RR_TLAS_WAVES_PER_SIMD : RR_FUSED_WAVES
         const uint32_t packed = unorm8(acc.x) | (unorm8(acc.y) << 8) | (unorm8(acc.z) << 16) | 0xff000000u;
         const size_t o = a.compact_out == 0u ? (size_t)y * a.W + x
                                             : (size_t)tile_local * (TILE * TILE) + py * TILE + px;
-        out_rgba8[o] = packed;
+        if (a.compact_out == 2u) {               // RGB8 tiles for the gather: alpha is always 255, not worth a link byte
+            uint8_t* p3 = reinterpret_cast<uint8_t*>(out_rgba8) + o * 3;
+            p3[0] = (uint8_t)packed; p3[1] = (uint8_t)(packed >> 8); p3[2] = (uint8_t)(packed >> 16);
+        } else {
+            out_rgba8[o] = packed;
+        }
         if (out_f32) out_f32[o] = make_float4(acc.x, acc.y, acc.z, 1.0f);
     }
 
@@ -342,6 +347,10 @@ __global__ __launch_bounds__(256) void k_render_async(SceneDev sc, DispatchDev a
                     const uint32_t packed = unorm8(acc.x) | (unorm8(acc.y) << 8) | (unorm8(acc.z) << 16) | 0xff000000u;
                     const size_t o = a.compact_out == 0u ? (size_t)y * a.W + x
                                                          : (size_t)tile_local * (TILE * TILE) + py * TILE + px;
+                    if (a.compact_out == 2u) {
+                        uint8_t* p3 = reinterpret_cast<uint8_t*>(out_rgba8) + o * 3;
+                        p3[0] = (uint8_t)packed; p3[1] = (uint8_t)(packed >> 8); p3[2] = (uint8_t)(packed >> 16);
+                    } else
                     out_rgba8[o] = packed;
                     if (out_f32) out_f32[o] = make_float4(acc.x, acc.y, acc.z, 1.0f);
                     alive = false;
@@ -431,6 +440,23 @@ __global__ __launch_bounds__(256) void k_assemble_frames(const uint32_t* __restr
             gathered[rank * rank_stride + f * frame_stride + (size_t)tile_local * (TILE * TILE) + py * TILE + px];
 }
 
+// the same for RGB8 tiles (3 bytes per pixel in the gathered buffers); strides in bytes
+__global__ __launch_bounds__(256) void k_assemble_frames_rgb8(const uint8_t* __restrict__ gathered, uint32_t* __restrict__ frames,
+                                                              uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles,
+                                                              uint32_t world, size_t rank_stride_b, size_t frame_stride_b,
+                                                              size_t out_stride)
+{
+    const uint32_t tile = blockIdx.x >> 2, strip = blockIdx.x & 3u, f = blockIdx.y;
+    if (tile >= n_tiles) return;
+    const uint32_t rank = tile % world, tile_local = tile / world;
+    const uint32_t px = threadIdx.x & 31u, py = strip * 8u + (threadIdx.x >> 5);
+    const uint32_t x = (tile % tiles_x) * TILE + px, y = (tile / tiles_x) * TILE + py;
+    if (x < W && y < H) {
+        const uint8_t* p = gathered + rank * rank_stride_b + f * frame_stride_b + ((size_t)tile_local * (TILE * TILE) + py * TILE + px) * 3;
+        frames[f * out_stride + (size_t)y * W + x] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | 0xff000000u;
+    }
+}
+
 // ------------------------------------------------------------------------------------ launchers
 template <int STACK, int PEND, bool TLAS>
 static hipError_t launch_fused_spt(const SceneDev& sc, const DispatchDev& a, bool stats, hipStream_t s)
@@ -517,6 +543,16 @@ hipError_t launch_assemble_frames(const uint32_t* gathered, uint32_t* frames, ui
     if (n_tiles == 0 || n_frames == 0) return hipSuccess;
     hipLaunchKernelGGL(k_assemble_frames, dim3(n_tiles * 4u, n_frames), dim3(256), 0, s, gathered, frames, W, H, tiles_x,
                        n_tiles, world, rank_stride, frame_stride, out_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble_frames_rgb8(const uint8_t* gathered, uint32_t* frames, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles,
+                                       uint32_t world, size_t rank_stride_b, size_t frame_stride_b, size_t out_stride, uint32_t n_frames,
+                                       hipStream_t s)
+{
+    if (n_tiles == 0 || n_frames == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_assemble_frames_rgb8, dim3(n_tiles * 4u, n_frames), dim3(256), 0, s, gathered, frames, W, H, tiles_x,
+                       n_tiles, world, rank_stride_b, frame_stride_b, out_stride);
     return hipGetLastError();
 }
 

@@ -11,6 +11,7 @@ import numpy as np
 
 TILE = 32
 TILE_BYTES = TILE * TILE * 4
+TILE_BYTES_RGB8 = TILE * TILE * 3      # RR_DISPATCH_TILES_RGB8: alpha is always 255 and is not sent
 
 
 def tile_grid(width, height):
@@ -97,15 +98,18 @@ class ShardedFrames:
     RING = 3
     LANES = 2
 
-    def __init__(self, renderer, width, height, rank, world, device, frames_per_gather=8):
+    def __init__(self, renderer, width, height, rank, world, device, frames_per_gather=8, rgb8=True):
+        """rgb8: tiles travel as 3 bytes per pixel (a quarter less into rank 0, whose xGMI ingest is what bounds the
+        8-GPU frame rate); rank 0 restores RGBA8 while de-interleaving."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.r = renderer
         self.width, self.height, self.rank, self.world = width, height, rank, world
         self.F = int(frames_per_gather)
+        self.rgb8 = bool(rgb8)
         self.max_tiles = max_local_tiles(width, height, world)
-        self.frame_bytes = self.max_tiles * TILE_BYTES
+        self.frame_bytes = self.max_tiles * (TILE_BYTES_RGB8 if self.rgb8 else TILE_BYTES)
         renderer.set_tile_partition(rank, world)
         self.send = [torch.zeros(self.F * self.frame_bytes, dtype=torch.uint8, device=device) for _ in range(self.RING)]
         self.recv = [torch.zeros(world * self.F * self.frame_bytes, dtype=torch.uint8, device=device)
@@ -142,7 +146,8 @@ class ShardedFrames:
             work.wait()                     # current stream waits for RCCL's stream; the host does not
         if self.rank == 0:
             self.r.assemble_frames(self.recv[slot].data_ptr(), self.world, self.F * self.frame_bytes, self.frame_bytes,
-                                   nf, self.width, self.height, self.frames.data_ptr(), self.height * self.width * 4)
+                                   nf, self.width, self.height, self.frames.data_ptr(), self.height * self.width * 4,
+                                   rgb8=self.rgb8)
             self.last_batch = nf
             if self._on_frames is not None:     # consumer hook, ordered on the current stream (clone / encode / present)
                 self._on_frames(self.frames.view(self.F, self.height, self.width, 4)[:nf])
@@ -153,7 +158,7 @@ class ShardedFrames:
         assembled batch in frame order; the view is overwritten by the next batch."""
         self._on_frames = on_frames
         from .host import default_params
-        from ._capi import DISPATCH_KEEP_COUNTERS
+        from ._capi import DISPATCH_KEEP_COUNTERS, DISPATCH_TILES_RGB8
         base = params if params is not None else default_params()
         rendered = None        # (slot, nf, lane): launched, not yet joined / gathered
         gathering = None       # (slot, nf, work): gather in flight
@@ -167,6 +172,8 @@ class ShardedFrames:
                 setattr(p, f, getattr(base, f))
             if done > 0:
                 p.flags |= DISPATCH_KEEP_COUNTERS
+            if self.rgb8:
+                p.flags |= DISPATCH_TILES_RGB8
             angle = self.r.render_orbit_sharded(self.width, self.height, nf, self.send[slot].data_ptr(), self.frame_bytes,
                                                 angle=angle, angle_step=angle_step, params=p, frames_per_dispatch=nf,
                                                 lane=lane)

@@ -258,8 +258,9 @@ class Renderer:
         self._ck(self._L.rr_lane_join(self._h, lane), "rr_lane_join")
 
     def assemble_frames(self, gathered_ptr, world, rank_stride_bytes, frame_stride_bytes, n_frames, width, height,
-                        frames_ptr, out_stride_bytes):
-        self._ck(self._L.rr_assemble_frames(self._h, C.c_void_p(gathered_ptr), world, rank_stride_bytes,
+                        frames_ptr, out_stride_bytes, rgb8=False):
+        fn = self._L.rr_assemble_frames_rgb8 if rgb8 else self._L.rr_assemble_frames
+        self._ck(fn(self._h, C.c_void_p(gathered_ptr), world, rank_stride_bytes,
                                             frame_stride_bytes, n_frames, width, height, C.c_void_p(frames_ptr),
                                             out_stride_bytes), "rr_assemble_frames")
 

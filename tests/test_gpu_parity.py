@@ -571,7 +571,7 @@ def test_orbit_loop_matches_draw_frame_sequence(gpu):
 
 
 # ------------------------------------------------------------------------------- N > 1 pipeline
-def _sharded_worker(rank, world, port, backend, out):
+def _sharded_worker(rank, world, port, backend, out, rgb8=True):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -584,7 +584,7 @@ def _sharded_worker(rank, world, port, backend, out):
     r.set_stream(torch.cuda.current_stream().cuda_stream)
     r.load_scene(m.verts, m.indices, env)
     W, H, K, F = 250, 130, 13, 2                   # 7 batches: every buffer set and both lanes are reused
-    sf = rr.dist.ShardedFrames(r, W, H, rank, world, torch.device("cuda", 0), frames_per_gather=F)
+    sf = rr.dist.ShardedFrames(r, W, H, rank, world, torch.device("cuda", 0), frames_per_gather=F, rgb8=rgb8)
     seen = []
     rays = sf.render_orbit(K, angle=0.01, params=rr.default_params(max_refract=8),
                            on_frames=(lambda fr: seen.append(fr.clone())) if rank == 0 else None)
@@ -613,10 +613,11 @@ def _sharded_worker(rank, world, port, backend, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo")])
-def test_sharded_frames_pipeline(tmp_path, world, backend):
-    """render -> (RCCL | gloo-staged) gather of F frames -> rr_assemble_frames, pipelined over batches,
-    equals frame-by-frame single-GPU rendering.  world 2 runs two processes on the one card."""
+@pytest.mark.parametrize("world,backend,rgb8", [(1, "nccl", True), (2, "gloo", True), (2, "gloo", False)])
+def test_sharded_frames_pipeline(tmp_path, world, backend, rgb8):
+    """render -> (RCCL | gloo-staged) gather of F frames -> rr_assemble_frames[_rgb8], pipelined over batches,
+    equals frame-by-frame single-GPU rendering.  world 2 runs two processes on the one card; tiles travel as
+    RGB8 (the default) or RGBA8."""
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as sk:
@@ -624,7 +625,7 @@ def test_sharded_frames_pipeline(tmp_path, world, backend):
         port = sk.getsockname()[1]
     out = str(tmp_path / "ok.npy")
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, backend, out)) for r in range(world)]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, backend, out, rgb8)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

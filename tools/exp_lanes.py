@@ -15,7 +15,7 @@ r = rr.Renderer(0)
 r.set_stream(torch.cuda.current_stream().cuda_stream)
 r.load_scene(m.verts, m.indices, procedural_env(2048, 1024, seed=0))
 r.set_tile_partition(0, world)
-p = rr.default_params(max_refract=8, max_reflect=2)
+p = rr.default_params(max_refract=8, max_reflect=2, flags=rr.DISPATCH_TILES_RGB8 if os.environ.get("RGB8") else 0)
 fb = max_local_tiles(W, H, world) * TILE_BYTES
 for F in ([int(sys.argv[2])] if len(sys.argv) > 2 else [8, 16, 64]):
     bufs = [torch.zeros(F * fb, dtype=torch.uint8, device="cuda") for _ in range(3)]
