@@ -34,7 +34,8 @@ typedef enum rr_status {
     RR_ERR_STATE = 5,            /* call order violated (e.g. dispatch before build) */
     RR_ERR_IO = 6,
     RR_ERR_UNSUPPORTED = 7,      /* parameter outside what the kernels are built for */
-    RR_ERR_TRAVERSAL_OVERFLOW = 8/* a traversal stack overflowed: result invalid */
+    RR_ERR_TRAVERSAL_OVERFLOW = 8/* sticky device error flag of a dispatch (reserved: the kernels size the traversal
+                                  * stack from the built tree and deeper trees are refused at build time) */
 } rr_status;
 
 /* Vertex record: Mesh.hpp:6-11 == RayTracing.hlsl:5-9.  32 bytes, stride of t2. */
@@ -94,7 +95,7 @@ typedef struct rr_stats {
     uint64_t tri_tests;           /* triangle records fetched (48 B each)    */
     uint64_t pixels;              /* pixels this context rendered (last dispatch, or all frames of rr_render_orbit) */
     uint32_t stats_valid;         /* 1 if the last dispatch ran with RR_DISPATCH_COLLECT_STATS */
-    uint32_t traversal_overflow;  /* sticky error flag of the last dispatch */
+    uint32_t traversal_overflow;  /* sticky device error flag of the last dispatch (0 unless a kernel raised it) */
     uint32_t bvh_depth;           /* deepest BLAS / TLAS leaf */
     uint32_t reserved;
 } rr_stats;
