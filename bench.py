@@ -194,8 +194,10 @@ def main():
             k1ms, k1n = r.kernel_time()
         achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))      # the latest round's PMC passes
+        tpath = cands[-1] if cands else ""
+        if tpath:
             try:
                 tj = json.load(open(tpath))
                 if tj.get("frames_per_launch") == F:
