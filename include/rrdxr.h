@@ -241,6 +241,12 @@ int  rr_kernel_time(rr_context* ctx, float* sum_ms, uint32_t* n_launches);
 /* exact counters of the last dispatch (blocks until it finished) */
 int  rr_get_stats(rr_context* ctx, rr_stats* out);
 
+/* Page-lock a caller-owned host buffer (e.g. the back buffer rr_read_frame copies into) so that read-backs run at
+ * PCIe speed instead of through the runtime's staging copies; unregister before freeing it.  The reference's
+ * readback heap plays this role (a CPU-visible committed resource, RefractionDemo.cpp:596-609 present path). */
+int  rr_host_register(rr_context* ctx, void* p, size_t bytes);
+int  rr_host_unregister(rr_context* ctx, void* p);
+
 /* TraceRay on caller-supplied rays (host arrays), same traversal code as the render path.
  * Stands for RayTracing.hlsl:60,106,121 in isolation; used by the parity tests. */
 int  rr_trace_rays(rr_context* ctx, const rr_ray* rays, uint32_t n, rr_hit* hits);

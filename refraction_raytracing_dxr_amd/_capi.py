@@ -103,6 +103,8 @@ SYMBOLS = {
     "rr_kernel_time": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "rr_trace_rays": (C.c_int, [_P, _P, C.c_uint32, _P]),
     "rr_download_blas": (C.c_int, [_P, C.c_uint32, _P, C.POINTER(C.c_uint32), _P, C.POINTER(C.c_uint32)]),
+    "rr_host_register": (C.c_int, [_P, _P, C.c_size_t]),
+    "rr_host_unregister": (C.c_int, [_P, _P]),
     "rr_download_qnodes": (C.c_int, [_P, C.c_uint32, _P, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
     "rr_default_dispatch_params": (None, [C.POINTER(DispatchParams)]),
     "rr_host_camera_orbit": (C.c_int, [C.c_float] * 5 + [C.POINTER(SceneConstants)]),

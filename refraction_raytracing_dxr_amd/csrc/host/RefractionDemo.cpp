@@ -12,6 +12,7 @@ Mesh cubeMesh;                               // the reference's name for its one
 Options g_opt;
 float g_angle = 0.01f;                       // static float angle (RefractionDemo.cpp:555)
 std::vector<uint8_t> g_back;
+bool g_back_pinned = false;
 std::string g_err;
 
 int fail(int code, const char* what)
@@ -52,7 +53,9 @@ int initialize(const Options& opt)
     inst.blas = geo.mesh_id;
     if ((rc = rr_build_tlas(g_ctx, &inst, 1)) != RR_OK) return fail(rc, "rr_build_tlas");
 
+    if (g_back_pinned) { rr_host_unregister(g_ctx, g_back.data()); g_back_pinned = false; }
     g_back.assign((size_t)opt.width * opt.height * 4, 0);
+    g_back_pinned = rr_host_register(g_ctx, g_back.data(), g_back.size()) == RR_OK;     // best effort: pageable works too
     return RR_OK;
 }
 
@@ -95,7 +98,10 @@ const char* lastError() { return g_err.c_str(); }
 
 void shutdown()
 {
-    if (g_ctx) { rr_destroy(g_ctx); g_ctx = nullptr; }
+    if (g_ctx) {
+        if (g_back_pinned) { rr_host_unregister(g_ctx, g_back.data()); g_back_pinned = false; }
+        rr_destroy(g_ctx); g_ctx = nullptr;
+    }
 }
 
 } // namespace RefractionDemo

@@ -1118,6 +1118,22 @@ int rr_download_blas(rr_context* ctx, uint32_t mesh_id, void* nodes, uint32_t* n
     return RR_OK;
 }
 
+int rr_host_register(rr_context* ctx, void* p, size_t bytes)
+{
+    if (int r = use_device(ctx)) return r;
+    if (!p || bytes == 0) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_host_register: null buffer");
+    RR_HIP(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return RR_OK;
+}
+
+int rr_host_unregister(rr_context* ctx, void* p)
+{
+    if (int r = use_device(ctx)) return r;
+    if (!p) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_host_unregister: null buffer");
+    RR_HIP(hipHostUnregister(p));
+    return RR_OK;
+}
+
 int rr_download_qnodes(rr_context* ctx, uint32_t mesh_id, void* qnodes, uint32_t* n_nodes, float grid_org_cell[6])
 {
     if (int r = use_device(ctx)) return r;
