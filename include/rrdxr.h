@@ -194,6 +194,15 @@ int  rr_render_orbit(rr_context* ctx, uint32_t width, uint32_t height, const rr_
                      float* angle, float angle_step, uint32_t n_frames, uint32_t frames_per_dispatch,
                      float fov_y, float aspect, float zn, float zf);
 
+/* The same loop with every frame delivered to host memory: frame k lands at host_rgba8 + k*W*H*4.  Launches
+ * alternate between two (or rr_set_frames_in_flight) device regions and each finished region is copied out on
+ * its own stream while the next launch renders -- the CPU-GPU overlap the reference notes it lacks
+ * (RefractionDemo.cpp:519-521).  Blocking: all n_frames are in host memory on return.  Page-lock the buffer
+ * (rr_host_register) for full PCIe speed. */
+int  rr_render_orbit_to_host(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispatch_params* params,
+                             float* angle, float angle_step, uint32_t n_frames, uint32_t frames_per_dispatch,
+                             float fov_y, float aspect, float zn, float zf, uint8_t* host_rgba8);
+
 /* How many launches of rr_render_orbit / rr_render_orbit_sharded may be in flight at once (1..4, default 1 =
  * strictly one after the other, like the reference's fence wait per frame, RefractionDemo.cpp:611).  With 2,
  * consecutive launches go to two internal streams and write to two output regions, so the few long-running

@@ -86,6 +86,8 @@ SYMBOLS = {
     "rr_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "rr_render_orbit": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(DispatchParams), C.POINTER(C.c_float),
                                   C.c_float, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "rr_render_orbit_to_host": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(DispatchParams), C.POINTER(C.c_float),
+                                          C.c_float, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "rr_render_orbit_sharded": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(DispatchParams), C.POINTER(C.c_float),
                                           C.c_float, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float,
                                           _P, C.c_uint64]),

@@ -91,6 +91,21 @@ int pump(int n_frames, int frames_per_dispatch, int in_flight, rr_stats* stats)
     return RR_OK;
 }
 
+// The frame loop with every frame delivered to host memory (frames[k*w*h*4 ...]), read-back overlapped with
+// rendering (rr_render_orbit_to_host).  `frames` must hold n_frames frames; page-lock it for full PCIe speed.
+int stream(int n_frames, int frames_per_dispatch, int in_flight, uint8_t* frames)
+{
+    if (!g_ctx) return fail(RR_ERR_STATE, "initialize first");
+    if (n_frames <= 0 || frames_per_dispatch <= 0 || !frames) return fail(RR_ERR_INVALID_ARGUMENT, "stream: bad arguments");
+    int rc = rr_set_frames_in_flight(g_ctx, (uint32_t)in_flight);
+    if (rc != RR_OK) return fail(rc, "rr_set_frames_in_flight");
+    rc = rr_render_orbit_to_host(g_ctx, (uint32_t)g_opt.width, (uint32_t)g_opt.height, &g_opt.dispatch, &g_angle, g_opt.angle_step,
+                                 (uint32_t)n_frames, (uint32_t)frames_per_dispatch, g_opt.fov_y, g_opt.aspect, g_opt.zn, g_opt.zf, frames);
+    if (rc != RR_OK) return fail(rc, "rr_render_orbit_to_host");
+    std::memcpy(g_back.data(), frames + (size_t)(n_frames - 1) * g_back.size(), g_back.size());
+    return RR_OK;
+}
+
 const std::vector<uint8_t>& backBuffer() { return g_back; }
 rr_context* context() { return g_ctx; }
 float currentAngle() { return g_angle; }

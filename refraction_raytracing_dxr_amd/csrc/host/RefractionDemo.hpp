@@ -29,6 +29,8 @@ int initialize(const Options& opt);       // RefractionDemo.cpp:513-553; returns
 int drawFrame();                          // RefractionDemo.cpp:557-612; returns rr_status
 // the frame loop as one call: no per-frame wait or read-back, `in_flight` launches overlapping (1..4)
 int pump(int n_frames, int frames_per_dispatch, int in_flight, rr_stats* stats);
+// the frame loop with every frame copied to host memory while the next ones render; frames: n_frames*w*h*4 bytes
+int stream(int n_frames, int frames_per_dispatch, int in_flight, uint8_t* frames);
 // the frame drawFrame just produced (RGBA8, width*height*4), i.e. what Present would have shown
 const std::vector<uint8_t>& backBuffer();
 rr_context* context();

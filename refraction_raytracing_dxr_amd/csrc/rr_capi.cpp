@@ -852,7 +852,7 @@ namespace {
 // buffer in one copy; the frames are then dispatched in batches of `batch` depth slices.
 int orbit_impl(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispatch_params* params, float* angle,
                float angle_step, uint32_t n_frames, uint32_t batch, float fov_y, float aspect, float zn, float zf,
-               uint32_t* ext_tiles, size_t ext_stride_elems)
+               uint32_t* ext_tiles, size_t ext_stride_elems, uint8_t* host_out = nullptr)
 {
     if (!angle) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "render_orbit: null angle");
     if (n_frames == 0) return RR_OK;
@@ -873,6 +873,11 @@ int orbit_impl(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispat
     // one overlap the start of the next.  Not for timed dispatches (their durations must be exclusive).
     uint32_t lanes = ctx->frames_in_flight < n_batches ? ctx->frames_in_flight : n_batches;
     if ((p.flags & RR_DISPATCH_TIME_KERNEL) || getenv("RR_DEBUG_DIAG")) lanes = 1;
+    if (host_out) {          // streaming to host: the copy of one region overlaps the rendering of the other
+        if (ext_tiles || ctx->tile_world != 1 || (p.flags & RR_DISPATCH_FLOAT_OUTPUT))
+            return fail(ctx, RR_ERR_UNSUPPORTED, "render_orbit_to_host: whole RGBA8 frames of an unsharded context only");
+        lanes = ctx->frames_in_flight > 2 ? ctx->frames_in_flight : 2;
+    }
     if (lanes <= 1) {
         for (uint32_t k = 0; k < n_frames; k += batch) {
             const uint32_t d = n_frames - k < batch ? n_frames - k : batch;
@@ -905,6 +910,11 @@ int orbit_impl(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispat
         uint32_t* ext = ext_tiles ? ext_tiles + (size_t)k * ext_stride_elems : nullptr;
         ctx->stream = ctx->lane_stream[b % lanes];
         rc = dispatch_impl(ctx, width, height, d, ctx->d_cams + k, p, ext, ext_stride_elems, true, b % lanes, batch);
+        if (rc == RR_OK && host_out) {      // same lane: the region is not rendered into again before this copy is done
+            const size_t fb = (size_t)width * height * 4;
+            hipError_t e = hipMemcpyAsync(host_out + (size_t)k * fb, ctx->d_rgba8 + ctx->frame_base, (size_t)d * fb, hipMemcpyDeviceToHost, ctx->stream);
+            if (e != hipSuccess) rc = fail(ctx, RR_ERR_DEVICE, "render_orbit_to_host: copy", e);
+        }
         ctx->stream = main_stream;
     }
     for (uint32_t l = 0; l < lanes; ++l) {                          // join: the caller's stream is ordered after every lane
@@ -924,6 +934,21 @@ int rr_render_orbit(rr_context* ctx, uint32_t width, uint32_t height, const rr_d
     if (int r = use_device(ctx)) return r;
     return orbit_impl(ctx, width, height, params, angle, angle_step, n_frames, frames_per_dispatch, fov_y, aspect, zn, zf,
                       nullptr, 0);
+}
+
+int rr_render_orbit_to_host(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispatch_params* params, float* angle,
+                            float angle_step, uint32_t n_frames, uint32_t frames_per_dispatch, float fov_y, float aspect, float zn,
+                            float zf, uint8_t* host_rgba8)
+{
+    if (int r = use_device(ctx)) return r;
+    if (!host_rgba8) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_render_orbit_to_host: null host buffer");
+    if (int r = orbit_impl(ctx, width, height, params, angle, angle_step, n_frames, frames_per_dispatch, fov_y, aspect, zn, zf,
+                           nullptr, 0, host_rgba8)) return r;
+    RR_HIP(hipStreamSynchronize(ctx->stream));          // every frame is in host memory on return
+    uint32_t err = 0;
+    RR_HIP(hipMemcpy(&err, &ctx->d_cnt->error, 4, hipMemcpyDeviceToHost));
+    if (err) return fail(ctx, RR_ERR_TRAVERSAL_OVERFLOW, "device error flag set: frames invalid");
+    return RR_OK;
 }
 
 int rr_render_orbit_sharded(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispatch_params* params, float* angle,

@@ -231,6 +231,24 @@ class Renderer:
         self.width, self.height = width, height
         return a.value
 
+    def render_orbit_to_host(self, width, height, n_frames, angle=0.01, angle_step=0.01, params=None, frames_per_dispatch=16,
+                             fov_y=FOV_Y, aspect=ASPECT, zn=1.0, zf=125.0, pin=True):
+        """The drawFrame loop with every frame delivered to host memory (copies overlap rendering).
+        -> uint8 [n_frames, h, w, 4]; blocks until all frames have arrived."""
+        p = params if params is not None else default_params()
+        a = C.c_float(float(np.float32(angle)))
+        out = np.empty((n_frames, height, width, 4), np.uint8)
+        pinned = pin and self._L.rr_host_register(self._h, out.ctypes.data, out.nbytes) == 0
+        try:
+            self._ck(self._L.rr_render_orbit_to_host(self._h, width, height, C.byref(p), C.byref(a), float(np.float32(angle_step)),
+                                                     n_frames, frames_per_dispatch, fov_y, aspect, zn, zf, out.ctypes.data),
+                     "rr_render_orbit_to_host")
+        finally:
+            if pinned:
+                self._L.rr_host_unregister(self._h, out.ctypes.data)
+        self.width, self.height = width, height
+        return out
+
     def render_orbit_sharded(self, width, height, n_frames, tiles_ptr, frame_stride_bytes, angle=0.01,
                              angle_step=0.01, params=None, frames_per_dispatch=1, fov_y=FOV_Y, aspect=ASPECT, zn=1.0,
                              zf=125.0, lane=None):

@@ -570,6 +570,30 @@ def test_orbit_loop_matches_draw_frame_sequence(gpu):
         gpu.set_frames_in_flight(5)
 
 
+def test_orbit_streamed_to_host_equals_draw_frame_sequence(gpu):
+    """rr_render_orbit_to_host: every frame of the loop lands in host memory (copy of one region overlapping the next
+    launch); same bytes as dispatch + read_frame per frame, for several batch sizes incl. a ragged last batch."""
+    m = load("shell.obj")
+    env = procedural_env(128, 64, seed=23)
+    gpu_scene(gpu, [m], env)
+    W, H, K = 200, 150, 11
+    p = rr.default_params()
+    ref = []
+    a = np.float32(0.01)
+    for k in range(K):
+        gpu.set_camera(rr.camera_orbit(a))
+        gpu.dispatch_rays(W, H, p)
+        ref.append(gpu.read_frame().copy())
+        a = np.float32(a + np.float32(0.01))
+    ref = np.stack(ref)
+    for F, fl, pin in ((1, 1, True), (3, 2, True), (4, 3, False), (16, 1, True)):
+        gpu.set_frames_in_flight(fl)
+        got = gpu.render_orbit_to_host(W, H, K, params=p, frames_per_dispatch=F, pin=pin)
+        assert got.shape == ref.shape and np.array_equal(got, ref), (F, fl)
+    gpu.set_frames_in_flight(1)
+    assert np.array_equal(gpu.read_frame(slice=(K - 1) % 16), ref[-1])          # the last launch is still readable
+
+
 # ------------------------------------------------------------------------------- N > 1 pipeline
 def _sharded_worker(rank, world, port, backend, out, rgb8=True):
     import torch
@@ -735,6 +759,13 @@ def test_rrdemo_cli(tmp_path, env_png):
     assert seq.returncode == 0 and pump.returncode == 0, pump.stderr
     assert "7 frames of 256x192" in pump.stdout and "3 in flight" in pump.stdout
     assert open(tmp_path / "p_006.ppm", "rb").read() == open(tmp_path / "s_006.ppm", "rb").read()
+    # every frame streamed to host memory with overlapped copies: the same seven frames as drawFrame's
+    strm = subprocess.run([exe, "--mesh", O.asset("shell.obj"), "--env", str(hdr), "--size", "256x192", "--frames", "7", "--stream",
+                           "--frames-per-dispatch", "3", "--in-flight", "2", "--out", str(tmp_path / "t_%03d.ppm")],
+                          capture_output=True, text=True, timeout=120)
+    assert strm.returncode == 0 and "fps delivered to" in strm.stdout, strm.stderr
+    for k in range(7):
+        assert open(tmp_path / ("t_%03d.ppm" % k), "rb").read() == open(tmp_path / ("s_%03d.ppm" % k), "rb").read()
     bad = subprocess.run([exe, "--mesh", str(tmp_path / "missing.obj"), "--env", str(hdr)], capture_output=True, text=True)
     assert bad.returncode == 1 and "mesh could not be loaded" in bad.stderr
 
