@@ -1027,8 +1027,9 @@ int rr_assemble_frames_rgb8(rr_context* ctx, const void* d_gathered, uint32_t wo
                             uint64_t out_stride_bytes)
 {
     if (int r = use_device(ctx)) return r;
-    if (!d_gathered || !d_frames || world == 0 || width == 0 || height == 0 || (out_stride_bytes & 3u))
-        return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_assemble_frames_rgb8: bad arguments");
+    if (!d_gathered || !d_frames || world == 0 || width == 0 || height == 0 ||
+        ((rank_stride_bytes | frame_stride_bytes | out_stride_bytes | (uint64_t)(uintptr_t)d_gathered) & 3u))
+        return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_assemble_frames_rgb8: bad arguments (strides and buffers are 4-byte aligned)");
     uint32_t tx, nt, local, mx;
     tile_counts(width, height, 0, world, tx, nt, local, mx);
     if (frame_stride_bytes < (uint64_t)mx * TILE * TILE * 3 || out_stride_bytes < (uint64_t)width * height * 4)

@@ -440,20 +440,38 @@ __global__ __launch_bounds__(256) void k_assemble_frames(const uint32_t* __restr
             gathered[rank * rank_stride + f * frame_stride + (size_t)tile_local * (TILE * TILE) + py * TILE + px];
 }
 
-// the same for RGB8 tiles (3 bytes per pixel in the gathered buffers); strides in bytes
+// the same for RGB8 tiles (3 bytes per pixel in the gathered buffers); strides in bytes.  One workgroup per tile and
+// frame, one thread per group of four pixels of a tile row: 12 contiguous bytes in, one 16-byte store out (rank 0 runs
+// this for every gathered batch while it also renders its own share, so it is written for bandwidth).
+// vec4: W % 4 == 0 (a group never straddles the right edge and its raster address is 16-byte aligned).
+template <bool VEC4>
 __global__ __launch_bounds__(256) void k_assemble_frames_rgb8(const uint8_t* __restrict__ gathered, uint32_t* __restrict__ frames,
                                                               uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles,
                                                               uint32_t world, size_t rank_stride_b, size_t frame_stride_b,
                                                               size_t out_stride)
 {
-    const uint32_t tile = blockIdx.x >> 2, strip = blockIdx.x & 3u, f = blockIdx.y;
+    const uint32_t tile = blockIdx.x, f = blockIdx.y;
     if (tile >= n_tiles) return;
     const uint32_t rank = tile % world, tile_local = tile / world;
-    const uint32_t px = threadIdx.x & 31u, py = strip * 8u + (threadIdx.x >> 5);
+    const uint32_t py = threadIdx.x >> 3, px = (threadIdx.x & 7u) * 4u;
     const uint32_t x = (tile % tiles_x) * TILE + px, y = (tile / tiles_x) * TILE + py;
-    if (x < W && y < H) {
-        const uint8_t* p = gathered + rank * rank_stride_b + f * frame_stride_b + ((size_t)tile_local * (TILE * TILE) + py * TILE + px) * 3;
-        frames[f * out_stride + (size_t)y * W + x] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | 0xff000000u;
+    if (y >= H || x >= W) return;
+    const uint8_t* p = gathered + rank * rank_stride_b + f * frame_stride_b + ((size_t)tile_local * (TILE * TILE) + py * TILE + px) * 3;
+    const uint32_t* p4 = reinterpret_cast<const uint32_t*>(p);                 // 12-byte group: 4-byte aligned
+    const uint32_t w0 = p4[0], w1 = p4[1], w2 = p4[2];
+    uint4 o;
+    o.x = (w0 & 0x00ffffffu) | 0xff000000u;
+    o.y = (((w0 >> 24) | (w1 << 8)) & 0x00ffffffu) | 0xff000000u;
+    o.z = (((w1 >> 16) | (w2 << 16)) & 0x00ffffffu) | 0xff000000u;
+    o.w = (w2 >> 8) | 0xff000000u;
+    uint32_t* dst = frames + f * out_stride + (size_t)y * W + x;
+    if (VEC4) {
+        *reinterpret_cast<uint4*>(dst) = o;
+    } else {
+        dst[0] = o.x;
+        if (x + 1 < W) dst[1] = o.y;
+        if (x + 2 < W) dst[2] = o.z;
+        if (x + 3 < W) dst[3] = o.w;
     }
 }
 
@@ -551,8 +569,11 @@ hipError_t launch_assemble_frames_rgb8(const uint8_t* gathered, uint32_t* frames
                                        hipStream_t s)
 {
     if (n_tiles == 0 || n_frames == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_assemble_frames_rgb8, dim3(n_tiles * 4u, n_frames), dim3(256), 0, s, gathered, frames, W, H, tiles_x,
-                       n_tiles, world, rank_stride_b, frame_stride_b, out_stride);
+    const bool vec4 = (W % 4u) == 0u && (out_stride % 4u) == 0u && (reinterpret_cast<uintptr_t>(frames) % 16u) == 0u;
+    if (vec4) hipLaunchKernelGGL(k_assemble_frames_rgb8<true>, dim3(n_tiles, n_frames), dim3(256), 0, s, gathered, frames, W, H, tiles_x,
+                                 n_tiles, world, rank_stride_b, frame_stride_b, out_stride);
+    else      hipLaunchKernelGGL(k_assemble_frames_rgb8<false>, dim3(n_tiles, n_frames), dim3(256), 0, s, gathered, frames, W, H, tiles_x,
+                                 n_tiles, world, rank_stride_b, frame_stride_b, out_stride);
     return hipGetLastError();
 }
 

@@ -595,7 +595,7 @@ def test_orbit_streamed_to_host_equals_draw_frame_sequence(gpu):
 
 
 # ------------------------------------------------------------------------------- N > 1 pipeline
-def _sharded_worker(rank, world, port, backend, out, rgb8=True):
+def _sharded_worker(rank, world, port, backend, out, rgb8=True, W=250):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -607,7 +607,7 @@ def _sharded_worker(rank, world, port, backend, out, rgb8=True):
     r = rr.Renderer(0)
     r.set_stream(torch.cuda.current_stream().cuda_stream)
     r.load_scene(m.verts, m.indices, env)
-    W, H, K, F = 250, 130, 13, 2                   # 7 batches: every buffer set and both lanes are reused
+    H, K, F = 130, 13, 2                           # 7 batches: every buffer set and both lanes are reused
     sf = rr.dist.ShardedFrames(r, W, H, rank, world, torch.device("cuda", 0), frames_per_gather=F, rgb8=rgb8)
     seen = []
     rays = sf.render_orbit(K, angle=0.01, params=rr.default_params(max_refract=8),
@@ -637,11 +637,11 @@ def _sharded_worker(rank, world, port, backend, out, rgb8=True):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,backend,rgb8", [(1, "nccl", True), (2, "gloo", True), (2, "gloo", False)])
-def test_sharded_frames_pipeline(tmp_path, world, backend, rgb8):
+@pytest.mark.parametrize("world,backend,rgb8,W", [(1, "nccl", True, 250), (2, "gloo", True, 256), (2, "gloo", False, 250)])
+def test_sharded_frames_pipeline(tmp_path, world, backend, rgb8, W):
     """render -> (RCCL | gloo-staged) gather of F frames -> rr_assemble_frames[_rgb8], pipelined over batches,
     equals frame-by-frame single-GPU rendering.  world 2 runs two processes on the one card; tiles travel as
-    RGB8 (the default) or RGBA8."""
+    RGB8 (the default; W = 256 takes the 16-byte-store path of the de-interleave, W = 250 the ragged one) or RGBA8."""
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as sk:
@@ -649,7 +649,7 @@ def test_sharded_frames_pipeline(tmp_path, world, backend, rgb8):
         port = sk.getsockname()[1]
     out = str(tmp_path / "ok.npy")
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, backend, out, rgb8)) for r in range(world)]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, backend, out, rgb8, W)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
