@@ -270,6 +270,10 @@ FRAME_CASES = [
     ("monkey.obj", 160, 120, 4.0, dict(max_refract=16, max_reflect=3)),   # parked-ray depth > 2
     ("ott.obj", 160, 120, 0.01, dict(max_refract=8)),
     ("monkey.obj", 33, 31, 1.0, dict(max_refract=0)),                # every hit is terminal -> black
+    ("cube.obj", 1, 1, 0.01, dict()),                                # a single pixel
+    ("monkey.obj", 2049, 3, 0.4, dict(max_refract=6)),               # wider than high: 65 tiles, one partial row and column
+    ("shell.obj", 5, 600, 0.01, dict(max_refract=8, ior=1.5)),       # higher than wide, another index of refraction
+    ("sphere.obj", 96, 96, 1.2, dict(max_refract=8, ior=0.8)),       # ior < 1: total internal reflection on entry
 ]
 
 
