@@ -141,6 +141,81 @@ def test_trace_rays_bit_exact_vs_brute_force(gpu, name, n):
     assert n_hit > n // 20
 
 
+def _soup(kind, n, seed):
+    """awkward geometry for the builder and the quantised boxes (vertex records, identity indices)"""
+    rng = np.random.default_rng(seed)
+    if kind == "flat":                     # every triangle in the plane z = 0.25: zero extent on one axis
+        P = rng.uniform(-2, 2, (n, 3, 3)); P[..., 2] = 0.25
+    elif kind == "far":                    # small mesh far from the origin: coordinates ~1e3, extent ~1
+        P = rng.uniform(-0.5, 0.5, (n, 3, 3)) * 0.2 + rng.uniform(-0.5, 0.5, (n, 1, 3)) + np.array([1000.0, -2000.0, 500.0])
+    elif kind == "mixed":                  # huge and tiny triangles, slivers, a few degenerate ones
+        c = rng.uniform(-3, 3, (n, 1, 3))
+        P = c + rng.normal(size=(n, 3, 3)) * rng.choice([1e-4, 1e-2, 0.3, 2.0], (n, 1, 1))
+        P[::17, 1] = P[::17, 0]            # zero-area: two equal vertices
+        P[5::29, 2] = (P[5::29, 0] + P[5::29, 1]) / 2          # zero-area: collinear
+    else:                                  # "line": all centroids on one line (Morton codes collide massively)
+        t = rng.uniform(-2, 2, (n, 1, 1))
+        P = t * np.array([1.0, 1.0, 1.0]) + rng.normal(size=(n, 3, 3)) * 0.01
+    v = np.zeros(n * 3, rr.VERTEX_DTYPE)
+    v["position"] = P.reshape(-1, 3).astype(np.float32)
+    v["norm"] = (0, 0, 1)
+    return v, np.arange(n * 3, dtype=np.uint32)
+
+
+@pytest.mark.parametrize("kind,n", [("flat", 300), ("far", 400), ("mixed", 700), ("line", 500), ("mixed", 1)])
+@pytest.mark.parametrize("fast_build", [False, True])
+def test_trace_rays_awkward_geometry_vs_brute_force(gpu, kind, n, fast_build):
+    """flat, far-away, wildly mixed-size / degenerate and collinear triangle soups: closest hit through the GPU
+    hierarchy (both builders, boxes on the 16-bit grid) == the oracle's brute force, bit for bit"""
+    verts, idx = _soup(kind, n, seed=n + len(kind))
+    mid = gpu.upload_mesh(verts, idx)
+    gpu.build_blas(mid, fast_build=fast_build)
+    gpu.build_tlas(rr.make_instances(meshes=[mid]))
+    s = O.Scene()
+    s.add_mesh(verts, idx)
+    rng = np.random.default_rng(7)
+    P = verts["position"].astype(np.float64)
+    lo, hi = P.min(0), P.max(0)
+    ctr, ext = (lo + hi) / 2, max(float((hi - lo).max()), 1e-3)
+    m_rays = 1500
+    rays = np.zeros(m_rays, rr.RAY_DTYPE)
+    o = ctr + rng.normal(size=(m_rays, 3)) * ext
+    tgt = P[rng.integers(0, len(P), m_rays)] + rng.normal(size=(m_rays, 3)) * ext * 0.02     # aim near real vertices
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays["origin"], rays["dir"] = o.astype(np.float32), d.astype(np.float32)
+    rays["origin"][:6] = (ctr + np.array([(-3, 0, 0), (3, 0, 0), (0, -3, 0), (0, 3, 0), (0, 0, -3), (0, 0, 3)]) * ext).astype(np.float32)
+    rays["dir"][:6] = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]           # axis-aligned, some in-plane
+    rays["tmin"] = 1e-4
+    rays["tmax"] = 1e6
+    rays["flags"] = rng.choice([rr.RAY_FLAG_CULL_BACK, rr.RAY_FLAG_CULL_FRONT, 0], m_rays)
+    hits = gpu.trace_rays(rays)
+    n_hit = 0
+    for k in range(m_rays):
+        h = s.trace(rays["origin"][k], rays["dir"][k], 1e-4, 1e6, int(rays["flags"][k]), use_bvh=0)
+        g = hits[k]
+        assert bool(g["hit"]) == bool(h.hit), "ray %d" % k
+        if h.hit:
+            n_hit += 1
+            assert g["prim"] == h.prim and np.float32(g["t"]).view(np.uint32) == np.float32(h.t).view(np.uint32)
+    assert n_hit >= (20 if n > 1 else 0)          # (the single triangle of "mixed, 1" is a degenerate one: no hit at all)
+
+
+def test_builds_are_deterministic(gpu):
+    """same mesh, two builds: identical fp32 and quantised hierarchies (the PLOC merge order comes from scans,
+    the Karras tree from sorted unique keys; nothing depends on atomics order)"""
+    m = load("ott.obj")
+    got = []
+    for _ in range(2):
+        for fast_build in (False, True):
+            mid = gpu.upload_mesh(m.verts, m.indices)
+            gpu.build_blas(mid, fast_build=fast_build)
+            nodes, tris = gpu.download_blas(mid)
+            q, org, cell = gpu.download_qnodes(mid)
+            got.append((nodes.tobytes(), tris.tobytes(), q.tobytes(), org.tobytes(), cell.tobytes()))
+    assert got[0] == got[2] and got[1] == got[3] and got[0] != got[1]
+
+
 @pytest.mark.parametrize("name", ["cube.obj", "monkey.obj", "ott.obj"])
 def test_quantised_nodes_contain_the_fp32_boxes(gpu, name):
     """Traversal reads 32-byte nodes on a 16-bit grid of the mesh bounds.  The box test only has to be conservative:
