@@ -115,6 +115,10 @@ struct rr_context {
     std::vector<hipEvent_t> kev;     // pairs
     uint32_t kev_used = 0;
 
+    // experimental queue-per-bounce renderer (RR_DEBUG_KERNEL=wavefront)
+    WfBuffers wf = { { nullptr, nullptr }, nullptr, nullptr, nullptr, 0 };
+    size_t    wf_pixels = 0;
+
     // trace_rays scratch
     rr_ray_dev* d_rays = nullptr;
     rr_hit_dev* d_hits = nullptr;
@@ -315,6 +319,7 @@ int rr_destroy(rr_context* ctx)
     }
     for (MeshRes& m : ctx->meshes) { dfree(m.d_verts); dfree(m.d_idx); dfree(m.nodes); dfree(m.qnodes); dfree(m.tris); dfree(m.nrms); }
     dfree(ctx->d_env); dfree(ctx->d_insts); dfree(ctx->d_pool_nodes); dfree(ctx->d_pool_qnodes); dfree(ctx->d_pool_tris); dfree(ctx->d_pool_nrms); dfree(ctx->d_rgba8); dfree(ctx->d_f32);
+    dfree(ctx->wf.q[0]); dfree(ctx->wf.q[1]); dfree(ctx->wf.slots); dfree(ctx->wf.hit_list); dfree(ctx->wf.counts);
     dfree(ctx->d_assembled); dfree(ctx->d_cnt); dfree(ctx->d_rays); dfree(ctx->d_hits); dfree(ctx->d_cams);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
@@ -726,8 +731,26 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         RR_HIP(hipEventRecord(ctx->kev[(size_t)ctx->kev_used * 2], ctx->stream));
     }
     int stack_sel = need <= 16 ? 16 : need <= 24 ? 24 : need <= 32 ? 32 : 64;
+    static const bool want_wavefront = [] { const char* e = getenv("RR_DEBUG_KERNEL"); return e && !strcmp(e, "wavefront"); }();
+    const bool wavefront = want_wavefront && ctx->single_identity && !compact && !want_f32 && !stats && p.max_reflect <= 2 && p.max_refract < 62;
+    if (wavefront) {        // experiment: queue-per-bounce kernels; buffers sized for this dispatch
+        const size_t px = (size_t)width * height * depth;
+        if (px > ctx->wf_pixels) {
+            RR_HIP(hipStreamSynchronize(ctx->stream));
+            dfree(ctx->wf.q[0]); dfree(ctx->wf.q[1]); dfree(ctx->wf.slots); dfree(ctx->wf.hit_list); dfree(ctx->wf.counts);
+            ctx->wf_pixels = 0;
+            ctx->wf.cap = (uint32_t)std::min<size_t>(px + 65536, 0x7fffffffu);     // a generation never holds two rays per pixel here
+            RR_HIP(hipMalloc(&ctx->wf.q[0], (size_t)ctx->wf.cap * 48));
+            RR_HIP(hipMalloc(&ctx->wf.q[1], (size_t)ctx->wf.cap * 48));
+            RR_HIP(hipMalloc(&ctx->wf.slots, px * 64));
+            RR_HIP(hipMalloc(&ctx->wf.hit_list, px * 4));
+            RR_HIP(hipMalloc(&ctx->wf.counts, 64 * 4));
+            ctx->wf_pixels = px;
+        }
+    }
     if (const char* ov = getenv("RR_DEBUG_STACK")) { const int v = atoi(ov); if (v >= (int)need) stack_sel = v; }   // experiments only; never below the tree depth (the kernels do not check)
-    RR_HIP(launch_render_fused(sc, a, stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream));
+    if (wavefront) RR_HIP(launch_render_wavefront(sc, a, ctx->wf, stack_sel, ctx->stream));
+    else RR_HIP(launch_render_fused(sc, a, stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream));
     if (timed) {
         RR_HIP(hipEventRecord(ctx->kev[(size_t)ctx->kev_used * 2 + 1], ctx->stream));
         ++ctx->kev_used;

@@ -24,6 +24,17 @@ hipError_t launch_assemble_frames_rgb8(const uint8_t* gathered, uint32_t* frames
                                        uint32_t world, size_t rank_stride_b, size_t frame_stride_b, size_t out_stride, uint32_t n_frames,
                                        hipStream_t s);
 
+// ---- experimental queue-per-bounce renderer (rr_render.hip, RR_DEBUG_KERNEL=wavefront; single identity instance,
+// max_reflect <= 2): ray queues (48 B records, ping-pong), four (w, texel) slots per pixel, the list of covered pixels
+struct WfBuffers {
+    float4*   q[2];        // cap records of 3 x float4 each
+    float4*   slots;       // [pixel index][4]: one slot per leaf of the pixel's ray tree, in depth-first order
+    uint32_t* hit_list;    // pixel indices whose primary ray hit
+    uint32_t* counts;      // [0] unused, [g] rays queued for bounce g (1..62), [63] covered pixels
+    uint32_t  cap;         // queue capacity in rays
+};
+hipError_t launch_render_wavefront(const SceneDev& sc, const DispatchDev& a, const WfBuffers& wf, int stack, hipStream_t s);
+
 // ---- rr_bvh_build.hip
 // Scratch + outputs of one LBVH build over n primitives (triangles of a mesh, or instances).
 struct BuildBuffers {

@@ -475,6 +475,189 @@ __global__ __launch_bounds__(256) void k_assemble_frames_rgb8(const uint8_t* __r
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Experimental queue-per-bounce ("wavefront path tracing") form of the same renderer, for comparison with the
+// fused kernel (RR_DEBUG_KERNEL=wavefront).  One kernel per ray generation: rays of bounce g are read from a queue,
+// traced and shaded; children go to the queue of bounce g+1 (one atomic per wave and child kind).  A pixel's ray
+// tree branches only while count < max_reflect, so with max_reflect <= 2 it has at most four leaves; leaf k (in the
+// recursion's depth-first order: refraction before reflection) writes its (weight, texel) to slot k of the pixel, and
+// a last kernel sums the four slots in order -- the same fma sequence as the fused kernel, bit for bit, whatever
+// order the queues were filled in.
+struct WfRay { f3 O, D; float w; uint32_t pix, count, slot; bool outside; };
+
+__device__ __forceinline__ void wf_store(float4* q, uint32_t i, const WfRay& r)
+{
+    q[(size_t)i * 3 + 0] = make_float4(r.O.x, r.O.y, r.O.z, r.w);
+    q[(size_t)i * 3 + 1] = make_float4(r.D.x, r.D.y, r.D.z, __uint_as_float(r.pix));
+    q[(size_t)i * 3 + 2] = make_float4(__uint_as_float(r.count | (r.outside ? 0x10000u : 0u) | (r.slot << 20)), 0.0f, 0.0f, 0.0f);
+}
+__device__ __forceinline__ WfRay wf_load(const float4* q, uint32_t i)
+{
+    const float4 a = q[(size_t)i * 3 + 0], b = q[(size_t)i * 3 + 1], c = q[(size_t)i * 3 + 2];
+    WfRay r;
+    r.O = mk3(a.x, a.y, a.z); r.w = a.w; r.D = mk3(b.x, b.y, b.z); r.pix = __float_as_uint(b.w);
+    const uint32_t m = __float_as_uint(c.x);
+    r.count = m & 0xffffu; r.outside = (m & 0x10000u) != 0u; r.slot = m >> 20;
+    return r;
+}
+// append the rays of the lanes with `have` set: one atomic per wave
+__device__ __forceinline__ void wf_push(const WfBuffers& wf, int gen, bool have, const WfRay& r, uint32_t* err)
+{
+    const unsigned long long m = __ballot(have);
+    if (m == 0ull) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int first = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane == first) base = atomicAdd(&wf.counts[gen], (uint32_t)__popcll(m));
+    base = __shfl(base, first, 64);
+    const uint32_t idx = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (have) { if (idx < wf.cap) wf_store(wf.q[gen & 1], idx, r); else *err = 1u; }
+}
+
+// ClosestHit for one lane: emits up to two children (refracted first).  Returns false for a terminal hit.
+__device__ __forceinline__ void wf_shade_hit(const SceneDev& sc, const DispatchDev& a, const WfRay& in, const HitRec& h,
+                                             bool& refr, bool& refl, WfRay& c1, WfRay& c2)
+{
+    refr = false; refl = false;
+    if ((int)in.count >= a.max_refract) return;                       // hlsl:82 (payload.color stays 0)
+    const f3 N = shading_normal<false>(sc, h);
+    const f3 X = mk3(fmaf(h.t, in.D.x, in.O.x), fmaf(h.t, in.D.y, in.O.y), fmaf(h.t, in.D.z, in.O.z));
+    const f3 Nf = in.outside ? N : neg3(N);
+    const float R0 = (0.2f / 2.2f) * (0.2f / 2.2f);
+    const float b = 1.0f - dot3(in.D, Nf);
+    const float b2 = b * b, b4 = b2 * b2;
+    const float R = (R0 * (1.0f - R0)) * (b4 * b);
+    const float eta = in.outside ? a.inv_ior : a.ior;
+    f3 d1;
+    refr = refract_ray(d1, in.D, Nf, eta);
+    refl = (int)in.count < a.max_reflect;
+    f3 d2 = mk3(0.0f, 0.0f, 0.0f);
+    if (refl) d2 = normalize3(reflect_ray(in.D, Nf));
+    const uint32_t bit = in.count < 2u ? (2u >> in.count) : 0u;       // the reflected branch at depth 0 / 1 owns slots 2,3 / 1,3
+    c1.O = X; c1.D = d1; c1.pix = in.pix; c1.count = in.count + 1u; c1.slot = in.slot;
+    c2.O = X; c2.D = d2; c2.pix = in.pix; c2.count = in.count + 1u; c2.slot = in.slot | bit; c2.outside = in.outside;
+    if (refr) { c1.w = in.w * (1.0f - R); c1.outside = !in.outside; c2.w = in.w * R; }
+    else { c1.w = 0.0f; c1.outside = in.outside; c2.w = in.w * R; }
+}
+
+template <int STACK>
+__global__ __launch_bounds__(256, RR_FUSED_WAVES_PER_SIMD(STACK)) void k_wf_primary(SceneDev sc, DispatchDev a, WfBuffers wf)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t* stk = lds + wave * (STACK * 64) + lane;
+    const uint32_t frame = blockIdx.x % a.n_frames;
+    uint32_t tile_local, strip;
+    block_to_tile(blockIdx.x / a.n_frames, tile_local, strip);
+    const bool tile_ok = tile_local < a.n_local_tiles;
+    const uint32_t tile = tile_local * a.tile_world + a.tile_rank;
+    const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const uint32_t lx = compact1by1(lane), ly = compact1by1(lane >> 1);
+    const uint32_t px = wave * 8u + lx, py = strip * 8u + ly;
+    const uint32_t x = tx * TILE + px, y = ty * TILE + py;
+    const bool valid = tile_ok && x < a.W && y < a.H;
+    const CamDev& cb = a.cams[frame];
+    uint32_t err = 0;
+    bool refr = false, refl = false;
+    WfRay c1, c2;
+    c1.O = c1.D = c2.O = c2.D = mk3(0.0f, 0.0f, 0.0f); c1.w = c2.w = 0.0f; c1.pix = c2.pix = 0u; c1.count = c2.count = 0u;
+    c1.slot = c2.slot = 0u; c1.outside = c2.outside = true;
+    if (valid) {
+        WfRay r;
+        r.O = mk3(cb.cam[0], cb.cam[1], cb.cam[2]);
+        r.D = camera_ray_dir(cb.M, x, y, a.W, a.H);
+        r.w = 1.0f; r.count = 0u; r.slot = 0u; r.outside = true;
+        r.pix = (uint32_t)((size_t)frame * a.frame_stride + (size_t)y * a.W + x);
+        HitRec h;
+        TravCounters cnt; cnt.nodes = 0; cnt.tris = 0;
+        trace_scene<false, false>(sc, r.O, r.D, a.tmin_p, a.tmax_p, CULL_BACK, h, stk, cnt);
+        if (!h.hit) {                                            // the pixel's only leaf: acc = fma(1, texel, 0)
+            const f3 e = env_lookup(sc, r.D);
+            const f3 acc = mk3(fmaf(1.0f, e.x, 0.0f), fmaf(1.0f, e.y, 0.0f), fmaf(1.0f, e.z, 0.0f));
+            a.out_rgba8[r.pix] = unorm8(acc.x) | (unorm8(acc.y) << 8) | (unorm8(acc.z) << 16) | 0xff000000u;
+        } else {
+            wf_shade_hit(sc, a, r, h, refr, refl, c1, c2);
+            if (!refr && !refl) a.out_rgba8[r.pix] = 0xff000000u;                    // no child: black
+            else {
+                const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                float4* sl = wf.slots + (size_t)r.pix * 4;
+                sl[0] = z; sl[1] = z; sl[2] = z; sl[3] = z;
+            }
+        }
+    }
+    // covered pixels and their children (wave-aggregated appends)
+    {
+        const bool cov = refr || refl;
+        const unsigned long long m = __ballot(cov);
+        if (m) {
+            const int first = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if ((int)lane == first) base = atomicAdd(&wf.counts[63], (uint32_t)__popcll(m));
+            base = __shfl(base, first, 64);
+            if (cov) wf.hit_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = c2.pix;
+        }
+    }
+    wf_push(wf, 1, refr, c1, &err);
+    wf_push(wf, 1, refl, c2, &err);
+    if (err) atomicOr(a.error_flag, 1u);
+}
+
+template <int STACK>
+__global__ __launch_bounds__(256, RR_FUSED_WAVES_PER_SIMD(STACK)) void k_wf_bounce(SceneDev sc, DispatchDev a, WfBuffers wf, int gen)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t* stk = lds + wave * (STACK * 64) + lane;
+    uint32_t n = wf.counts[gen];
+    n = n < wf.cap ? n : wf.cap;
+    const float4* qin = wf.q[gen & 1];
+    uint32_t err = 0;
+    for (uint32_t base = (blockIdx.x * 4u + wave) * 64u; base < n; base += gridDim.x * 256u) {
+        const uint32_t i = base + lane;
+        bool refr = false, refl = false;
+        WfRay c1, c2;
+        c1.O = c1.D = c2.O = c2.D = mk3(0.0f, 0.0f, 0.0f); c1.w = c2.w = 0.0f; c1.pix = c2.pix = 0u; c1.count = c2.count = 0u;
+        c1.slot = c2.slot = 0u; c1.outside = c2.outside = true;
+        if (i < n) {
+            const WfRay r = wf_load(qin, i);
+            HitRec h;
+            TravCounters cnt; cnt.nodes = 0; cnt.tris = 0;
+            trace_scene<false, false>(sc, r.O, r.D, a.tmin_s, a.tmax_s, r.outside ? CULL_BACK : CULL_FRONT, h, stk, cnt);
+            if (!h.hit) {
+                const f3 e = env_lookup(sc, r.D);
+                wf.slots[(size_t)r.pix * 4 + r.slot] = make_float4(r.w, e.x, e.y, e.z);
+            } else {
+                wf_shade_hit(sc, a, r, h, refr, refl, c1, c2);
+            }
+        }
+        wf_push(wf, gen + 1, refr, c1, &err);
+        wf_push(wf, gen + 1, refl, c2, &err);
+    }
+    if (err) atomicOr(a.error_flag, 1u);
+}
+
+__global__ __launch_bounds__(256) void k_wf_resolve(DispatchDev a, WfBuffers wf)
+{
+    const uint32_t n = wf.counts[63];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                   // TraceRay calls of the dispatch: primaries + every queued ray
+        uint32_t rays = a.W * a.H * a.n_frames;
+        for (int g = 1; g < 63; ++g) rays += wf.counts[g];
+        atomicAdd(&a.ray_shards[0], rays);
+    }
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t pix = wf.hit_list[i];
+        const float4* sl = wf.slots + (size_t)pix * 4;
+        f3 acc = mk3(0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 s = sl[k];                              // an unused slot holds w = 0: fma(0, 0, acc) == acc
+            acc.x = fmaf(s.x, s.y, acc.x); acc.y = fmaf(s.x, s.z, acc.y); acc.z = fmaf(s.x, s.w, acc.z);
+        }
+        a.out_rgba8[pix] = unorm8(acc.x) | (unorm8(acc.y) << 8) | (unorm8(acc.z) << 16) | 0xff000000u;
+    }
+}
+
 // ------------------------------------------------------------------------------------ launchers
 template <int STACK, int PEND, bool TLAS>
 static hipError_t launch_fused_spt(const SceneDev& sc, const DispatchDev& a, bool stats, hipStream_t s)
@@ -575,6 +758,29 @@ hipError_t launch_assemble_frames_rgb8(const uint8_t* gathered, uint32_t* frames
     else      hipLaunchKernelGGL(k_assemble_frames_rgb8<false>, dim3(n_tiles, n_frames), dim3(256), 0, s, gathered, frames, W, H, tiles_x,
                                  n_tiles, world, rank_stride_b, frame_stride_b, out_stride);
     return hipGetLastError();
+}
+
+
+template <int STACK>
+static hipError_t launch_wavefront_s(const SceneDev& sc, const DispatchDev& a, const WfBuffers& wf, hipStream_t s)
+{
+    const size_t lds = (size_t)4 * STACK * 64 * sizeof(uint32_t);
+    hipError_t e = hipMemsetAsync(wf.counts, 0, 64 * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_wf_primary<STACK>), dim3(a.n_blocks), dim3(256), lds, s, sc, a, wf);
+    const uint32_t persistent = 256u * 6u;
+    for (int g = 1; g <= a.max_refract && g < 62; ++g)
+        hipLaunchKernelGGL((k_wf_bounce<STACK>), dim3(persistent), dim3(256), lds, s, sc, a, wf, g);
+    hipLaunchKernelGGL(k_wf_resolve, dim3(persistent), dim3(256), 0, s, a, wf);
+    return hipGetLastError();
+}
+
+hipError_t launch_render_wavefront(const SceneDev& sc, const DispatchDev& a, const WfBuffers& wf, int stack, hipStream_t s)
+{
+    if (stack <= 16) return launch_wavefront_s<16>(sc, a, wf, s);
+    if (stack <= 24) return launch_wavefront_s<24>(sc, a, wf, s);
+    if (stack <= 32) return launch_wavefront_s<32>(sc, a, wf, s);
+    return launch_wavefront_s<64>(sc, a, wf, s);
 }
 
 } // namespace rr

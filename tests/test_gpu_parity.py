@@ -19,6 +19,7 @@ from conftest import procedural_env
 
 pytestmark = pytest.mark.gpu
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FLOAT_TOL = 1e-4
 
 
@@ -199,6 +200,34 @@ def test_trace_rays_awkward_geometry_vs_brute_force(gpu, kind, n, fast_build):
             n_hit += 1
             assert g["prim"] == h.prim and np.float32(g["t"]).view(np.uint32) == np.float32(h.t).view(np.uint32)
     assert n_hit >= (20 if n > 1 else 0)          # (the single triangle of "mixed, 1" is a degenerate one: no hit at all)
+
+
+def test_experimental_wavefront_kernels_render_the_same_frames(tmp_path):
+    """RR_DEBUG_KERNEL=wavefront (queue-per-bounce kernels kept for comparison): bit-identical frames to
+    the fused kernel, whatever order the queues fill in.  Own processes: the switch is read once per process."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import refraction_raytracing_dxr_amd as rr\n"
+        "from refraction_raytracing_dxr_amd.synth import asset, procedural_env\n"
+        "r = rr.Renderer(0); out = []\n"
+        "for name, kw in (('monkey.obj', dict(max_refract=8)), ('sphere.obj', dict(max_refract=4, max_reflect=1)), ('cube.obj', dict())):\n"
+        "    m = rr.Mesh(); m.load(asset(name))\n"
+        "    r.load_scene(m.verts, m.indices, procedural_env(256, 128, seed=9))\n"
+        "    r.render_orbit(323, 181, 5, angle=0.3, params=rr.default_params(**kw), frames_per_dispatch=3)\n"
+        "    out += [r.read_frame(slice=0), r.read_frame(slice=1)]\n"
+        "    assert r.stats().traversal_overflow == 0\n"
+        "np.save(sys.argv[1], np.stack(out)); print(r.stats().rays)\n") % ROOT
+    res = {}
+    for k in ("fused", "wavefront"):
+        env = dict(os.environ, RR_DEBUG_KERNEL=k)
+        p = subprocess.run([sys.executable, "-c", code, str(tmp_path / (k + ".npy"))], capture_output=True, text=True, env=env, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[k] = (np.load(tmp_path / (k + ".npy")), int(p.stdout.split()[-1]))
+    assert np.array_equal(res["fused"][0], res["wavefront"][0])
+    assert res["fused"][1] == res["wavefront"][1]                      # and the same number of TraceRay calls
 
 
 def test_builds_are_deterministic(gpu):
