@@ -86,8 +86,8 @@ def cpu_baseline(mesh, env, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1536)
-    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=12288)     # 1.3 s of frames on one GPU: the timed region is not launch jitter
+    ap.add_argument("--warmup", type=int, default=192)      # three launches: both render lanes and all three buffer sets of the N>1 pipeline
     ap.add_argument("--depth1", action="store_true", help="also time the reference's shape, one DispatchRays per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-subdiv", action="store_true",
