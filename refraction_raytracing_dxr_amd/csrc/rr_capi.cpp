@@ -27,6 +27,32 @@ static_assert(sizeof(rr_instance_desc) == 64, "D3D12_RAYTRACING_INSTANCE_DESC");
 static_assert(sizeof(rr_scene_constants) == 80, "SceneConstants");
 static_assert(sizeof(rr_ray) == sizeof(rr_ray_dev) && sizeof(rr_hit) == sizeof(rr_hit_dev), "ray/hit ABI");
 
+// Optional roctx ranges around the coarse steps (build, dispatch, assemble) so that `rocprofv3 --marker-trace`
+// shows them next to the kernels.  The marker library is looked up at run time; without it the calls are no-ops.
+#include <dlfcn.h>
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        for (const char* lib : { "librocprofiler-sdk-roctx.so", "libroctx64.so" }) {
+            if (void* h = dlopen(lib, RTLD_LAZY | RTLD_LOCAL)) {
+                push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return;
+                push = nullptr; pop = nullptr;
+            }
+        }
+    }
+};
+const Roctx& roctx() { static const Roctx r; return r; }
+struct Range {
+    explicit Range(const char* name) { if (roctx().push) roctx().push(name); }
+    ~Range() { if (roctx().pop) roctx().pop(); }
+};
+} // namespace
+
 namespace {
 
 struct MeshRes {
@@ -433,6 +459,7 @@ int rr_build_blas(rr_context* ctx, uint32_t mesh_id) { return rr_build_blas_ex(c
 
 int rr_build_blas_ex(rr_context* ctx, uint32_t mesh_id, uint32_t flags)
 {
+    const Range range_("rr_build_blas");
     if (int r = use_device(ctx)) return r;
     if (mesh_id >= ctx->meshes.size()) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_build_blas: unknown mesh id");
     MeshRes& m = ctx->meshes[mesh_id];
@@ -471,6 +498,7 @@ int rr_build_blas_ex(rr_context* ctx, uint32_t mesh_id, uint32_t flags)
 
 int rr_build_tlas(rr_context* ctx, const rr_instance_desc* instances, uint32_t n)
 {
+    const Range range_("rr_build_tlas");
     if (int r = use_device(ctx)) return r;
     if (!instances || n == 0) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_build_tlas: need >= 1 instance");
     for (uint32_t i = 0; i < n; ++i) {
@@ -791,6 +819,7 @@ int upload_cams(rr_context* ctx, const rr_scene_constants* c, size_t n)
 
 int rr_dispatch_rays(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispatch_params* params)
 {
+    const Range range_("rr_dispatch_rays");
     if (int r = use_device(ctx)) return r;
     if (!ctx->cam_set) return fail(ctx, RR_ERR_STATE, "rr_dispatch_rays: rr_set_camera first");
     rr_dispatch_params p;
@@ -877,6 +906,7 @@ int orbit_impl(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispat
                float angle_step, uint32_t n_frames, uint32_t batch, float fov_y, float aspect, float zn, float zf,
                uint32_t* ext_tiles, size_t ext_stride_elems, uint8_t* host_out = nullptr)
 {
+    const Range range_("rr_render_orbit");
     if (!angle) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "render_orbit: null angle");
     if (n_frames == 0) return RR_OK;
     if (batch == 0) batch = 1;
@@ -1033,6 +1063,7 @@ int rr_assemble_frames(rr_context* ctx, const void* d_gathered, uint32_t world, 
                        uint64_t frame_stride_bytes, uint32_t n_frames, uint32_t width, uint32_t height, void* d_frames,
                        uint64_t out_stride_bytes)
 {
+    const Range range_("rr_assemble_frames");
     if (int r = use_device(ctx)) return r;
     if (!d_gathered || !d_frames || world == 0 || width == 0 || height == 0 || ((rank_stride_bytes | frame_stride_bytes | out_stride_bytes) & 3u))
         return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_assemble_frames: bad arguments");
@@ -1049,6 +1080,7 @@ int rr_assemble_frames_rgb8(rr_context* ctx, const void* d_gathered, uint32_t wo
                             uint64_t frame_stride_bytes, uint32_t n_frames, uint32_t width, uint32_t height, void* d_frames,
                             uint64_t out_stride_bytes)
 {
+    const Range range_("rr_assemble_frames_rgb8");
     if (int r = use_device(ctx)) return r;
     if (!d_gathered || !d_frames || world == 0 || width == 0 || height == 0 ||
         ((rank_stride_bytes | frame_stride_bytes | out_stride_bytes | (uint64_t)(uintptr_t)d_gathered) & 3u))
