@@ -151,7 +151,10 @@ def main():
         total_rays = st.rays
         overflow = st.traversal_overflow
     else:
-        sf = rr.dist.ShardedFrames(r, W, H, rank, world, torch.device("cuda", local_rank), args.frames_per_dispatch)
+        # a rank's share of a launch has 1/world of the blocks: keep launches long enough for their tails not to show
+        # (tools/exp_lanes.py, world 8: 113 us/frame-equivalent at 64 frames per launch, 108 at 256)
+        Fn = args.frames_per_dispatch * max(1, min(world // 2, 4))
+        sf = rr.dist.ShardedFrames(r, W, H, rank, world, torch.device("cuda", local_rank), Fn)
         sf.render_orbit(Wm, angle=0.01, params=params)
         barrier()
         t0 = time.perf_counter()
@@ -254,7 +257,7 @@ def main():
                                    "orbit angle 0.01*(k+1), seeded procedural 2048x1024 RGB32F env map",
                        "rays_per_frame": round(total_rays / K, 1),
                        "parallelism": "tiles32x32-roundrobin-x%d" % world,
-                       "frames_per_dispatch": F},
+                       "frames_per_dispatch": F if world == 1 else F * max(1, min(world // 2, 4))},
             "device_region_ms_per_step": round(region_ms / K, 5) if region_ms is not None else None,
             "roofline": roofline,
             "cpu_baseline": cpu,
