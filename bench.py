@@ -137,7 +137,13 @@ def main():
         torch.cuda.synchronize()
 
     F = max(1, args.frames_per_dispatch)
-    if world == 1:
+    # rehearsal switch: run the N > 1 code path (ShardedFrames + RCCL gather) with a single rank
+    force_sharded = world == 1 and os.environ.get("RR_BENCH_FORCE_SHARDED") == "1"
+    if force_sharded:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+    if world == 1 and not force_sharded:
         r.set_tile_partition(0, 1)
         r.render_orbit(W, H, Wm, angle=0.01, params=params, frames_per_dispatch=F)      # warmup, untimed
         barrier()
@@ -154,7 +160,7 @@ def main():
         # a rank's share of a launch has 1/world of the blocks: keep launches long enough for their tails not to show
         # (tools/exp_lanes.py, world 8: 113 us/frame-equivalent at 64 frames per launch, 108 at 256)
         Fn = args.frames_per_dispatch * max(1, min(world // 2, 4))
-        sf = rr.dist.ShardedFrames(r, W, H, rank, world, torch.device("cuda", local_rank), Fn)
+        sf = rr.dist.ShardedFrames(r, W, H, rank, world, torch.device("cuda", local_rank), Fn, always_collective=force_sharded)
         sf.render_orbit(Wm, angle=0.01, params=params)
         barrier()
         t0 = time.perf_counter()

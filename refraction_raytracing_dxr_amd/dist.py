@@ -98,7 +98,7 @@ class ShardedFrames:
     RING = 3
     LANES = 2
 
-    def __init__(self, renderer, width, height, rank, world, device, frames_per_gather=8, rgb8=True):
+    def __init__(self, renderer, width, height, rank, world, device, frames_per_gather=8, rgb8=True, always_collective=False):
         """rgb8: tiles travel as 3 bytes per pixel (a quarter less into rank 0, whose xGMI ingest is what bounds the
         8-GPU frame rate); rank 0 restores RGBA8 while de-interleaving."""
         import torch
@@ -119,11 +119,12 @@ class ShardedFrames:
         self.last_batch = 0
         self._on_frames = None
         self._via_host = world > 1 and dist.get_backend() == "gloo"     # test rigs without RCCL: stage through host
+        self._always_collective = bool(always_collective)               # world == 1: still go through dist.gather (tests)
 
     def _gather(self, slot, nf):
         n = nf * self.frame_bytes
         send = self.send[slot][:n]
-        if self.world == 1:
+        if self.world == 1 and not self._always_collective:
             self.recv[slot][:n].copy_(send)
             return None
         chunks = None

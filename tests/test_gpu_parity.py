@@ -716,7 +716,9 @@ def _sharded_worker(rank, world, port, backend, out, rgb8=True, W=250):
     r.set_stream(torch.cuda.current_stream().cuda_stream)
     r.load_scene(m.verts, m.indices, env)
     H, K, F = 130, 13, 2                           # 7 batches: every buffer set and both lanes are reused
-    sf = rr.dist.ShardedFrames(r, W, H, rank, world, torch.device("cuda", 0), frames_per_gather=F, rgb8=rgb8)
+    # world 1 under nccl: still issue the RCCL gather (async_op, views of the ring buffers), as the N > 1 ranks do
+    sf = rr.dist.ShardedFrames(r, W, H, rank, world, torch.device("cuda", 0), frames_per_gather=F, rgb8=rgb8,
+                               always_collective=(backend == "nccl"))
     seen = []
     rays = sf.render_orbit(K, angle=0.01, params=rr.default_params(max_refract=8),
                            on_frames=(lambda fr: seen.append(fr.clone())) if rank == 0 else None)
