@@ -758,7 +758,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         }
         RR_HIP(hipEventRecord(ctx->kev[(size_t)ctx->kev_used * 2], ctx->stream));
     }
-    int stack_sel = need <= 16 ? 16 : need <= 24 ? 24 : need <= 32 ? 32 : 64;
+    int stack_sel = need <= 26 ? 26 : need <= 31 ? 31 : need <= 39 ? 39 : 64;     // rr_render.hip: sizes that fill the LDS with 6 / 5 / 4 / 2 workgroups
     static const bool want_wavefront = [] { const char* e = getenv("RR_DEBUG_KERNEL"); return e && !strcmp(e, "wavefront"); }();
     const bool wavefront = want_wavefront && ctx->single_identity && !compact && !want_f32 && !stats && p.max_reflect <= 2 && p.max_refract < 62;
     if (wavefront) {        // experiment: queue-per-bounce kernels; buffers sized for this dispatch
@@ -1175,7 +1175,7 @@ int rr_trace_rays(rr_context* ctx, const rr_ray* rays, uint32_t n, rr_hit* hits)
     fill_scene(ctx, sc);
     RR_HIP(hipMemsetAsync(&ctx->d_cnt->error, 0, 4, ctx->stream));
     RR_HIP(hipMemcpyAsync(ctx->d_rays, rays, (size_t)n * sizeof(rr_ray_dev), hipMemcpyHostToDevice, ctx->stream));
-    RR_HIP(launch_trace_rays(sc, ctx->d_rays, n, ctx->d_hits, &ctx->d_cnt->error, scene_stack_need(ctx) <= 32 ? 32 : 64, ctx->stream));
+    RR_HIP(launch_trace_rays(sc, ctx->d_rays, n, ctx->d_hits, &ctx->d_cnt->error, scene_stack_need(ctx) <= 31 ? 31 : 64, ctx->stream));
     RR_HIP(hipMemcpyAsync(hits, ctx->d_hits, (size_t)n * sizeof(rr_hit_dev), hipMemcpyDeviceToHost, ctx->stream));
     uint32_t err = 0;
     RR_HIP(hipMemcpyAsync(&err, &ctx->d_cnt->error, 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -15,15 +15,16 @@
 #include "rr_device.h"
 #include "rr_launch.h"
 
-// minimum waves per SIMD the register allocator must leave room for.  Measured (Depth 64, us/frame): 4 waves
-// 123 / 214 / 180 on monkey / sphere / ott, 5 waves (96 VGPRs, no spill) 108 / 189 / 178, 6 waves (80 VGPRs,
-// 15 words spilled) 104 / 183 / 186.  A 32-entry stack (ott.obj) caps the CU at 5 workgroups anyway (LDS), so
-// only the shallow-tree instantiations ask for 6.
+// Stack sizes and waves per SIMD go together: a workgroup's four stacks take STACK KiB of LDS and a CU lets about
+// 156 KiB be allocated (tools/ubench_occupancy.hip: six workgroups are resident up to 26 624 B each, five up to
+// 31 744 B, four up to 40 960 B -- 32 768 B already drops to four).  So the instantiations are 26 entries (6 waves
+// per SIMD, 80 VGPRs), 31 (5 waves, 96 VGPRs), 39 (4 waves) and 64 (2 waves).  Measured at Depth 64, us/frame on
+// monkey / sphere: 4 waves 123 / 214, 5 waves 108 / 189, 6 waves (15 words spilled) 104 / 183.
 #ifndef RR_FUSED_WAVES_PER_SIMD
-#define RR_FUSED_WAVES_PER_SIMD(STACK) ((STACK) <= 24 ? 6 : 5)
+#define RR_FUSED_WAVES_PER_SIMD(STACK) ((STACK) <= 26 ? 6 : (STACK) <= 31 ? 5 : (STACK) <= 39 ? 4 : 2)
 #endif
 #ifndef RR_TLAS_WAVES_PER_SIMD
-#define RR_TLAS_WAVES_PER_SIMD 4
+#define RR_TLAS_WAVES_PER_SIMD(STACK) ((STACK) <= 39 ? 4 : 2)
 #endif
 
 namespace rr {
@@ -53,7 +54,7 @@ __device__ __forceinline__ void block_to_tile(uint32_t b, uint32_t& tile_local, 
 }
 
 template <int STACK, int PEND, bool STATS, bool TLAS, bool DIAG = false>
-__global__ __launch_bounds__(256, TLAS ? RR_TLAS_WAVES_PER_SIMD : RR_FUSED_WAVES_PER_SIMD(STACK)) void k_render_fused(SceneDev sc, DispatchDev a)
+__global__ __launch_bounds__(256, TLAS ? RR_TLAS_WAVES_PER_SIMD(STACK) : RR_FUSED_WAVES_PER_SIMD(STACK)) void k_render_fused(SceneDev sc, DispatchDev a)
 {
     __shared__ uint32_t diag_trips[12];    // per wave: internal trips, leaf trips, shading passes
     const unsigned long long diag_t0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -703,13 +704,13 @@ hipError_t launch_render_fused(const SceneDev& sc, const DispatchDev& a, int sta
 {
     if (a.n_blocks == 0) return hipSuccess;
     if (a.diag) {       // diagnostic builds of the reference-scene kernels (never used by the product path)
-        if (use_sync_kernel()) hipLaunchKernelGGL((k_render_fused<32, 2, false, false, true>), dim3(a.n_blocks), dim3(256), 4 * 32 * 64 * 4, s, sc, a);
-        else hipLaunchKernelGGL((k_render_async<32, 2, false, true>), dim3(a.n_blocks), dim3(256), 4 * 32 * 64 * 4, s, sc, a);
+        if (use_sync_kernel()) hipLaunchKernelGGL((k_render_fused<31, 2, false, false, true>), dim3(a.n_blocks), dim3(256), 4 * 31 * 64 * 4, s, sc, a);
+        else hipLaunchKernelGGL((k_render_async<31, 2, false, true>), dim3(a.n_blocks), dim3(256), 4 * 31 * 64 * 4, s, sc, a);
         return hipGetLastError();
     }
-    if (stack <= 16 && pend <= 2) return launch_fused_sp<16, 2>(sc, a, stats, s);
-    if (stack <= 24 && pend <= 2) return launch_fused_sp<24, 2>(sc, a, stats, s);
-    if (stack <= 32) return pend <= 2 ? launch_fused_sp<32, 2>(sc, a, stats, s) : launch_fused_sp<32, 8>(sc, a, stats, s);
+    if (stack <= 26 && pend <= 2) return launch_fused_sp<26, 2>(sc, a, stats, s);
+    if (stack <= 31) return pend <= 2 ? launch_fused_sp<31, 2>(sc, a, stats, s) : launch_fused_sp<31, 8>(sc, a, stats, s);
+    if (stack <= 39) return pend <= 2 ? launch_fused_sp<39, 2>(sc, a, stats, s) : launch_fused_sp<39, 8>(sc, a, stats, s);
     return pend <= 2 ? launch_fused_sp<64, 2>(sc, a, stats, s) : launch_fused_sp<64, 8>(sc, a, stats, s);
 }
 
@@ -723,7 +724,7 @@ hipError_t launch_trace_rays(const SceneDev& sc, const rr_ray_dev* rays, uint32_
                              int stack, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
-    if (stack <= 32) { if (sc.single_identity) launch_trace_st<32, false>(sc, rays, n, hits, err, s); else launch_trace_st<32, true>(sc, rays, n, hits, err, s); }
+    if (stack <= 31) { if (sc.single_identity) launch_trace_st<31, false>(sc, rays, n, hits, err, s); else launch_trace_st<31, true>(sc, rays, n, hits, err, s); }
     else             { if (sc.single_identity) launch_trace_st<64, false>(sc, rays, n, hits, err, s); else launch_trace_st<64, true>(sc, rays, n, hits, err, s); }
     return hipGetLastError();
 }
@@ -777,9 +778,8 @@ static hipError_t launch_wavefront_s(const SceneDev& sc, const DispatchDev& a, c
 
 hipError_t launch_render_wavefront(const SceneDev& sc, const DispatchDev& a, const WfBuffers& wf, int stack, hipStream_t s)
 {
-    if (stack <= 16) return launch_wavefront_s<16>(sc, a, wf, s);
-    if (stack <= 24) return launch_wavefront_s<24>(sc, a, wf, s);
-    if (stack <= 32) return launch_wavefront_s<32>(sc, a, wf, s);
+    if (stack <= 26) return launch_wavefront_s<26>(sc, a, wf, s);
+    if (stack <= 31) return launch_wavefront_s<31>(sc, a, wf, s);
     return launch_wavefront_s<64>(sc, a, wf, s);
 }
 

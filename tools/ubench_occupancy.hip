@@ -13,7 +13,7 @@ int main()
 {
     unsigned* d; (void)hipMalloc(&d, 1024);
     hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-    int ldss[] = {0, 8192, 16384, 24576, 32768, 40960, 65536, 81920};
+    int ldss[] = {0, 8192, 16384, 24576, 26624, 27648, 28672, 30720, 31744, 32256, 32768, 40960, 65536, 81920};
     for (int lds : ldss) {
         (void)hipFuncSetAttribute((const void*)k_wait, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         printf("lds %6d:", lds);
