@@ -953,6 +953,40 @@ def test_large_mesh_build_and_trace(gpu):
     assert np.array_equal(a[150:210, 280:360], ref["rgba8"][150:210, 280:360])
 
 
+@pytest.mark.parametrize("levels,fast_build,depth", [(2, True, 26), (2, False, 24), (3, False, 30)])
+def test_stack_size_boundaries(gpu, levels, fast_build, depth):
+    """The kernels carry no stack-overflow check: the host picks the 26 / 31 / 39 / 64-entry instantiation from the
+    built tree's depth.  Trees whose depth sits exactly on a boundary (26: the radix tree of the 15 472-triangle
+    monkey fills the 26-entry stack to the last entry) must still trace like brute force."""
+    from refraction_raytracing_dxr_amd.synth import subdivide
+    m = load("monkey.obj")
+    v, i = subdivide(m.verts, levels)
+    mid = gpu.upload_mesh(v, i)
+    gpu.build_blas(mid, fast_build=fast_build)
+    gpu.build_tlas(rr.make_instances(meshes=[mid]))
+    gpu.upload_envmap(procedural_env(32, 16))
+    gpu.set_camera(rr.camera_orbit(0.4))
+    gpu.dispatch_rays(64, 36, rr.default_params(flags=rr.DISPATCH_COLLECT_STATS))
+    assert gpu.stats().bvh_depth == depth
+    s = O.Scene()
+    s.add_mesh(v, i)
+    rays = random_rays(1200, seed=levels * 7 + depth)
+    hits = gpu.trace_rays(rays)
+    for k in range(len(rays)):
+        h = s.trace(rays["origin"][k], rays["dir"][k], float(rays["tmin"][k]), float(rays["tmax"][k]), int(rays["flags"][k]), use_bvh=1)
+        assert bool(hits["hit"][k]) == bool(h.hit), k
+        if h.hit:
+            assert hits["prim"][k] == h.prim and np.float32(hits["t"][k]).view(np.uint32) == np.float32(h.t).view(np.uint32)
+    # and a frame through the render kernel of that stack size: deterministic, every ray ends in a hit or a miss
+    gpu.set_tile_partition(0, 1)
+    gpu.dispatch_rays(320, 180, rr.default_params(max_refract=8, flags=rr.DISPATCH_COLLECT_STATS))
+    a = gpu.read_frame().copy()
+    st = gpu.stats()
+    assert st.hits + st.misses == st.rays and st.traversal_overflow == 0
+    gpu.dispatch_rays(320, 180, rr.default_params(max_refract=8))
+    assert np.array_equal(gpu.read_frame(), a)
+
+
 def test_subdivided_monkey_16k_frame_parity(gpu):
     """BASELINE's '~16k tri Suzanne' = monkey.obj midpoint-subdivided twice (15 472 tri): same surface,
     16x the hierarchy.  Float accumulator bit-equal to the oracle's path-weight mode; and since midpoint
