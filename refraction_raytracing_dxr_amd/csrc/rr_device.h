@@ -254,10 +254,30 @@ __device__ __forceinline__ void tri_test(const TriRec* __restrict__ tris, uint32
     if (U < 0.0f || V < 0.0f || U + V > ad) return;
     float t = T / ad;
     if (!(t > tmin)) return;
-    if (t < best.t || (t == best.t && best.hit && (inst < best.inst || (inst == best.inst && prim < best.prim)))) {
-        best.t = t; best.U = U; best.V = V; best.ad = ad; best.prim = prim; best.leaf = leaf; best.inst = inst;
+    // (the barycentrics of the winner are recomputed once, after the traversal: hit_attributes.  Carrying them through
+    // the loops costs four registers per lane; an exact tie needs the other triangle's primitive index, a rare load.)
+    if (t < best.t || (t == best.t && best.hit && (inst < best.inst || (inst == best.inst && prim < tris[best.leaf].prim)))) {
+        best.t = t; best.leaf = leaf; best.inst = inst;
         best.hit = true;
     }
+}
+
+// Attributes of the closest hit: the same operations, in the same order, as the test that accepted it (O, D: the ray in
+// the space of the triangle's BLAS), so U, V, ad have the very bits tri_test computed.
+__device__ __forceinline__ void hit_attributes(const TriRec* __restrict__ tris, f3 O, f3 D, HitRec& best)
+{
+    const float4* q = reinterpret_cast<const float4*>(tris + best.leaf);
+    float4 a = q[0], b = q[1], c = q[2];
+    f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
+    f3 pv = cross3(D, e2);
+    float det = dot3(e1, pv);
+    f3 tv = sub3(O, v0);
+    float U = dot3(tv, pv);
+    f3 qv = cross3(tv, e1);
+    float V = dot3(D, qv);
+    float ad = det;
+    if (det < 0.0f) { U = -U; V = -V; ad = -det; }
+    best.U = U; best.V = V; best.ad = ad; best.prim = __float_as_uint(a.w);
 }
 
 // "while-while" traversal with an early hand-over: called by the lanes still descending (exec = those lanes, so
@@ -312,6 +332,7 @@ __device__ __forceinline__ void trace_blas(const BlasDev& bl, f3 O, f3 D, float 
         }
         if (__ballot(node != TRAV_DONE) == 0ull) break;
     }
+    if (best.hit) hit_attributes(bl.tris, O, D, best);
 }
 
 __device__ __forceinline__ f3 xform_point(const float* m, f3 p)
@@ -384,6 +405,12 @@ __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, floa
                 node = (int)in.root;
             } else if (top > stk) { top -= STACK_STRIDE; node = (int)*top; } else node = TRAV_DONE;
         }
+    }
+    if (best.hit) {                             // the ray in the space of the instance that was hit, as at its entry
+        const InstDev& in = sc.insts[best.inst];
+        f3 Oh = O, Dh = D;
+        if (!in.identity) { Oh = xform_point(in.inv, O); Dh = xform_dir(in.inv, D); }
+        hit_attributes(sc.pool_tris, Oh, Dh, best);
     }
 }
 

@@ -295,6 +295,7 @@ __global__ __launch_bounds__(256) void k_render_async(SceneDev sc, DispatchDev a
                 } else {                                                  // ClosestHit, hlsl:79-125
                     if (STATS) ++n_hits;
                     if ((int)count < a.max_refract) {
+                        hit_attributes(sc.blas0.tris, O, D, h);
                         const f3 N = shading_normal<false>(sc, h);
                         const f3 X = mk3(fmaf(h.t, D.x, O.x), fmaf(h.t, D.y, O.y), fmaf(h.t, D.z, O.z));
                         const f3 Nf = outside ? N : neg3(N);
