@@ -163,7 +163,8 @@ def _soup(kind, n, seed):
     return v, np.arange(n * 3, dtype=np.uint32)
 
 
-@pytest.mark.parametrize("kind,n", [("flat", 300), ("far", 400), ("mixed", 700), ("line", 500), ("mixed", 1)])
+@pytest.mark.parametrize("kind,n", [("flat", 300), ("far", 400), ("mixed", 700), ("line", 500), ("mixed", 1), ("far", 2), ("flat", 3),
+                                    ("line", 5), ("mixed", 9), ("far", 33), ("flat", 64), ("mixed", 65)])
 @pytest.mark.parametrize("fast_build", [False, True])
 def test_trace_rays_awkward_geometry_vs_brute_force(gpu, kind, n, fast_build):
     """flat, far-away, wildly mixed-size / degenerate and collinear triangle soups: closest hit through the GPU
@@ -199,7 +200,7 @@ def test_trace_rays_awkward_geometry_vs_brute_force(gpu, kind, n, fast_build):
         if h.hit:
             n_hit += 1
             assert g["prim"] == h.prim and np.float32(g["t"]).view(np.uint32) == np.float32(h.t).view(np.uint32)
-    assert n_hit >= (20 if n > 1 else 0)          # (the single triangle of "mixed, 1" is a degenerate one: no hit at all)
+    assert n_hit >= (20 if n >= 100 else 0)       # (tiny soups offer little to hit; "mixed, 1" is a single degenerate triangle)
 
 
 def test_experimental_wavefront_kernels_render_the_same_frames(tmp_path):
