@@ -758,7 +758,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         }
         RR_HIP(hipEventRecord(ctx->kev[(size_t)ctx->kev_used * 2], ctx->stream));
     }
-    int stack_sel = need <= 26 ? 26 : need <= 31 ? 31 : need <= 39 ? 39 : 64;     // rr_render.hip: sizes that fill the LDS with 6 / 5 / 4 / 2 workgroups
+    int stack_sel = need <= 19 ? 19 : need <= 22 ? 22 : need <= 26 ? 26 : need <= 31 ? 31 : need <= 39 ? 39 : 64;     // rr_render.hip: sizes that fill the LDS with 6 / 5 / 4 / 2 workgroups
     static const bool want_wavefront = [] { const char* e = getenv("RR_DEBUG_KERNEL"); return e && !strcmp(e, "wavefront"); }();
     const bool wavefront = want_wavefront && ctx->single_identity && !compact && !want_f32 && !stats && p.max_reflect <= 2 && p.max_refract < 62;
     if (wavefront) {        // experiment: queue-per-bounce kernels; buffers sized for this dispatch
@@ -778,7 +778,12 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     }
     if (const char* ov = getenv("RR_DEBUG_STACK")) { const int v = atoi(ov); if (v >= (int)need) stack_sel = v; }   // experiments only; never below the tree depth (the kernels do not check)
     if (wavefront) RR_HIP(launch_render_wavefront(sc, a, ctx->wf, stack_sel, ctx->stream));
-    else RR_HIP(launch_render_fused(sc, a, stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream));
+    else {
+        // deep trees of small meshes: 16-bit stack entries keep eight waves per SIMD (LDS would otherwise allow 6/5/4)
+        const bool stack16 = ctx->single_identity && need > 19 && need <= 39 && !getenv("RR_DEBUG_STACK") &&
+                             ctx->meshes[(size_t)ctx->inst_host[0].blas].n_tris < 32768u;
+        RR_HIP(launch_render_fused(sc, a, stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream, stack16));
+    }
     if (timed) {
         RR_HIP(hipEventRecord(ctx->kev[(size_t)ctx->kev_used * 2 + 1], ctx->stream));
         ++ctx->kev_used;

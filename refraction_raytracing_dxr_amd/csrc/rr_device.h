@@ -205,10 +205,22 @@ __device__ __forceinline__ void box2_hit(const BoxRay& r, const NodeQ& n, float 
 // stack pointer is the LDS address of the next free entry; depth never exceeds the tree depth (near child
 // followed, far child pushed), and the host picks a stack at least that deep, so there is no overflow check.
 constexpr int STACK_STRIDE = 64;
+// Stack entries are child refs.  32-bit entries hold them as they are; 16-bit entries (meshes below 32 768 triangles:
+// a quarter of the LDS per wave, so deep trees keep eight waves per SIMD) hold node index or 0x8000 | leaf index.
+template <class E> struct StackCodec;
+template <> struct StackCodec<uint32_t> {
+    static __device__ __forceinline__ uint32_t enc(int ref) { return (uint32_t)ref; }
+    static __device__ __forceinline__ int dec(uint32_t v) { return (int)v; }
+};
+template <> struct StackCodec<uint16_t> {
+    static __device__ __forceinline__ uint16_t enc(int ref) { return ref >= 0 ? (uint16_t)((uint32_t)ref >> 5) : (uint16_t)(0x8000u | (uint32_t)~ref); }
+    static __device__ __forceinline__ int dec(uint16_t v) { return (v & 0x8000u) ? ~(int)(v & 0x7fffu) : (int)((uint32_t)v << 5); }
+};
 
 // one traversal step at an internal node: returns the next node (near child, or a popped entry, or
 // TRAV_DONE) and pushes the far child when both are hit.  top: next free entry, floor: lowest entry that may be popped.
-__device__ __forceinline__ int node_step(const BoxRay& br, const NodeQ& n, float tmin, float tmax, uint32_t*& top, const uint32_t* floor)
+template <class E>
+__device__ __forceinline__ int node_step(const BoxRay& br, const NodeQ& n, float tmin, float tmax, E*& top, const E* floor)
 {
     bool h0, h1;
     float tn0, tn1;
@@ -217,8 +229,8 @@ __device__ __forceinline__ int node_step(const BoxRay& br, const NodeQ& n, float
     const bool both = h0 && h1, swap = tn1 < tn0;
     const int nearc = (h0 && !(h1 && swap)) ? c0 : c1;
     int next = (h0 || h1) ? nearc : TRAV_DONE;
-    if (both) { *top = (uint32_t)(swap ? c0 : c1); top += STACK_STRIDE; }
-    if (!(h0 || h1) && top > floor) { top -= STACK_STRIDE; next = (int)*top; }
+    if (both) { *top = StackCodec<E>::enc(swap ? c0 : c1); top += STACK_STRIDE; }
+    if (!(h0 || h1) && top > floor) { top -= STACK_STRIDE; next = StackCodec<E>::dec(*top); }
     return next;
 }
 
@@ -297,13 +309,13 @@ __device__ __forceinline__ bool leaf_phase_due(int n_in)
 // "while-while" form: the lanes descend internal nodes (near child first, far child pushed) until enough of
 // them hold a leaf or have finished (leaf_phase_due); then the (expensive) triangle test is executed once for
 // all lanes that hold a leaf.
-template <bool STATS>
+template <bool STATS, class E>
 __device__ __forceinline__ void trace_blas(const BlasDev& bl, f3 O, f3 D, float tmin, uint32_t cull, uint32_t inst,
-                                           HitRec& best, uint32_t* stk, TravCounters& cnt, const Diag dg = Diag{ nullptr })
+                                           HitRec& best, E* stk, TravCounters& cnt, const Diag dg = Diag{ nullptr })
 {
     const BoxRay br = box_ray(O, D, bl.scale, bl.grid);
     const QNode* __restrict__ nodes = bl.nodes;
-    uint32_t* top = stk;
+    E* top = stk;
     int node = 0;
     for (;;) {
         // internal-node phase.  Lanes drop out as they reach a leaf (or finish); the phase ends for the whole wave
@@ -328,7 +340,7 @@ __device__ __forceinline__ void trace_blas(const BlasDev& bl, f3 O, f3 D, float 
             diag_trip(dg, 1);
             if (STATS) cnt.tris++;
             tri_test(bl.tris, (uint32_t)~node, O, D, tmin, cull, inst, best);
-            if (top > stk) { top -= STACK_STRIDE; node = (int)*top; } else node = TRAV_DONE;
+            if (top > stk) { top -= STACK_STRIDE; node = StackCodec<E>::dec(*top); } else node = TRAV_DONE;
         }
         if (__ballot(node != TRAV_DONE) == 0ull) break;
     }
@@ -352,17 +364,18 @@ __device__ __forceinline__ f3 xform_dir(const float* m, f3 p)
 // TLAS = false: the reference's scene, one BLAS.  TLAS = true: one loop over the flattened node pool;
 // reaching an instance leaf swaps the lane's ray for its object-space image (t is preserved: the
 // direction is not renormalised) and remembers the stack level, exhausting that level swaps it back.
-template <bool STATS, bool TLAS>
+template <bool STATS, bool TLAS, class E = uint32_t>
 __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, float tmin, float tmax, uint32_t flags,
-                                            HitRec& best, uint32_t* stk, TravCounters& cnt,
+                                            HitRec& best, E* stk_e, TravCounters& cnt,
                                             const Diag dg = Diag{ nullptr })
 {
     best.t = tmax; best.hit = false; best.prim = 0; best.leaf = 0; best.inst = 0; best.U = 0.0f; best.V = 0.0f;
     best.ad = 1.0f;
     if (!TLAS) {      // the reference's scene: one identity instance, mask 1, flags 0 (RefractionDemo.cpp:324-334)
-        trace_blas<STATS>(sc.blas0, O, D, tmin, flags, 0u, best, stk, cnt, dg);
+        trace_blas<STATS, E>(sc.blas0, O, D, tmin, flags, 0u, best, stk_e, cnt, dg);
         return;
     }
+    uint32_t* stk = reinterpret_cast<uint32_t*>(stk_e);      // the two-level loop always runs on 32-bit entries
     const QNode* __restrict__ nodes = sc.pool_nodes;
     constexpr uint32_t NO_INST = 0xffffffffu;
     BoxRay br = box_ray(O, D, sc.scale, sc.grid);

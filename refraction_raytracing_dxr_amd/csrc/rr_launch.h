@@ -11,7 +11,8 @@ struct rr_hit_dev { float t, u, v; uint32_t prim, inst, hit; };
 static_assert(sizeof(rr_ray_dev) == 48 && sizeof(rr_hit_dev) == 24, "ABI layout");
 
 // ---- rr_render.hip
-hipError_t launch_render_fused(const SceneDev& sc, const DispatchDev& a, int stack, int pend, bool stats, hipStream_t s);
+hipError_t launch_render_fused(const SceneDev& sc, const DispatchDev& a, int stack, int pend, bool stats, hipStream_t s,
+                               bool stack16 = false);
 hipError_t launch_trace_rays(const SceneDev& sc, const rr_ray_dev* rays, uint32_t n, rr_hit_dev* hits, uint32_t* err,
                              int stack, hipStream_t s);
 hipError_t launch_assemble_tiles(const uint32_t* gathered, uint32_t* frame, uint32_t W, uint32_t H, uint32_t tiles_x,

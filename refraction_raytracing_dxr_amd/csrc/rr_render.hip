@@ -21,7 +21,7 @@
 // per SIMD, 80 VGPRs), 31 (5 waves, 96 VGPRs), 39 (4 waves) and 64 (2 waves).  Measured at Depth 64, us/frame on
 // monkey / sphere: 4 waves 123 / 214, 5 waves 108 / 189, 6 waves (15 words spilled) 104 / 183.
 #ifndef RR_FUSED_WAVES_PER_SIMD
-#define RR_FUSED_WAVES_PER_SIMD(STACK) ((STACK) <= 26 ? 6 : (STACK) <= 31 ? 5 : (STACK) <= 39 ? 4 : 2)
+#define RR_FUSED_WAVES_PER_SIMD(STACK) ((STACK) <= 19 ? 8 : (STACK) <= 22 ? 7 : (STACK) <= 26 ? 6 : (STACK) <= 31 ? 5 : (STACK) <= 39 ? 4 : 2)
 #endif
 #ifndef RR_TLAS_WAVES_PER_SIMD
 #define RR_TLAS_WAVES_PER_SIMD(STACK) ((STACK) <= 39 ? 4 : 2)
@@ -53,8 +53,8 @@ __device__ __forceinline__ void block_to_tile(uint32_t b, uint32_t& tile_local, 
     strip = slot & 3u;
 }
 
-template <int STACK, int PEND, bool STATS, bool TLAS, bool DIAG = false>
-__global__ __launch_bounds__(256, TLAS ? RR_TLAS_WAVES_PER_SIMD(STACK) : RR_FUSED_WAVES_PER_SIMD(STACK)) void k_render_fused(SceneDev sc, DispatchDev a)
+template <int STACK, int PEND, bool STATS, bool TLAS, bool DIAG = false, class E = uint32_t>
+__global__ __launch_bounds__(256, TLAS ? RR_TLAS_WAVES_PER_SIMD(STACK) : sizeof(E) == 2 ? 8 : RR_FUSED_WAVES_PER_SIMD(STACK)) void k_render_fused(SceneDev sc, DispatchDev a)
 {
     __shared__ uint32_t diag_trips[12];    // per wave: internal trips, leaf trips, shading passes
     const unsigned long long diag_t0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256, TLAS ? RR_TLAS_WAVES_PER_SIMD(STACK) : RR_FUSE
     if (DIAG) __syncthreads();
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    uint32_t* stk = lds + wave * (STACK * 64) + lane;
+    E* stk = reinterpret_cast<E*>(lds) + wave * (STACK * 64) + lane;
 
     // Depth slices are interleaved block by block (block b renders slice b % Depth): measured on MI355X,
     // mixing the slices keeps every CU on a blend of cheap background waves and expensive mesh waves
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256, TLAS ? RR_TLAS_WAVES_PER_SIMD(STACK) : RR_FUSE
         float tmin = a.tmin_p, tmax = a.tmax_p;
         for (;;) {
             HitRec h;
-            trace_scene<STATS, TLAS>(sc, O, D, tmin, tmax, outside ? CULL_BACK : CULL_FRONT, h, stk, cnt,
+            trace_scene<STATS, TLAS, E>(sc, O, D, tmin, tmax, outside ? CULL_BACK : CULL_FRONT, h, stk, cnt,
                                             Diag{ DIAG ? &diag_trips[threadIdx.x >> 6] : nullptr });
             ++n_rays;
             if (DIAG) diag_trip(Diag{ &diag_trips[threadIdx.x >> 6] }, 2);
@@ -701,14 +701,29 @@ static hipError_t launch_fused_sp(const SceneDev& sc, const DispatchDev& a, bool
     return launch_async_sp<STACK, PEND>(sc, a, stats, s);
 }
 
-hipError_t launch_render_fused(const SceneDev& sc, const DispatchDev& a, int stack, int pend, bool stats, hipStream_t s)
+// reference-scene kernel on 16-bit stack entries (meshes below 32 768 triangles, trees of 20..39 levels): 39 entries are
+// 19 968 B per workgroup, eight workgroups per CU
+template <int PEND>
+static hipError_t launch_fused_s16(const SceneDev& sc, const DispatchDev& a, bool stats, hipStream_t s)
+{
+    const size_t lds = (size_t)4 * 39 * 64 * sizeof(uint16_t);
+    if (stats) hipLaunchKernelGGL((k_render_fused<39, PEND, true, false, false, uint16_t>), dim3(a.n_blocks), dim3(256), lds, s, sc, a);
+    else       hipLaunchKernelGGL((k_render_fused<39, PEND, false, false, false, uint16_t>), dim3(a.n_blocks), dim3(256), lds, s, sc, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_render_fused(const SceneDev& sc, const DispatchDev& a, int stack, int pend, bool stats, hipStream_t s, bool stack16)
 {
     if (a.n_blocks == 0) return hipSuccess;
+    if (stack16 && !a.diag && sc.single_identity && use_sync_kernel() && stack <= 39)
+        return pend <= 2 ? launch_fused_s16<2>(sc, a, stats, s) : launch_fused_s16<8>(sc, a, stats, s);
     if (a.diag) {       // diagnostic builds of the reference-scene kernels (never used by the product path)
         if (use_sync_kernel()) hipLaunchKernelGGL((k_render_fused<31, 2, false, false, true>), dim3(a.n_blocks), dim3(256), 4 * 31 * 64 * 4, s, sc, a);
         else hipLaunchKernelGGL((k_render_async<31, 2, false, true>), dim3(a.n_blocks), dim3(256), 4 * 31 * 64 * 4, s, sc, a);
         return hipGetLastError();
     }
+    if (stack <= 19 && pend <= 2) return launch_fused_sp<19, 2>(sc, a, stats, s);
+    if (stack <= 22 && pend <= 2) return launch_fused_sp<22, 2>(sc, a, stats, s);
     if (stack <= 26 && pend <= 2) return launch_fused_sp<26, 2>(sc, a, stats, s);
     if (stack <= 31) return pend <= 2 ? launch_fused_sp<31, 2>(sc, a, stats, s) : launch_fused_sp<31, 8>(sc, a, stats, s);
     if (stack <= 39) return pend <= 2 ? launch_fused_sp<39, 2>(sc, a, stats, s) : launch_fused_sp<39, 8>(sc, a, stats, s);
