@@ -780,8 +780,12 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     if (wavefront) RR_HIP(launch_render_wavefront(sc, a, ctx->wf, stack_sel, ctx->stream));
     else {
         // deep trees of small meshes: 16-bit stack entries keep eight waves per SIMD (LDS would otherwise allow 6/5/4)
-        const bool stack16 = ctx->single_identity && need > 19 && need <= 39 && !getenv("RR_DEBUG_STACK") &&
-                             ctx->meshes[(size_t)ctx->inst_host[0].blas].n_tris < 32768u;
+        bool stack16 = ctx->single_identity && need > 19 && need <= 39 && !getenv("RR_DEBUG_STACK") &&
+                       ctx->meshes[(size_t)ctx->inst_host[0].blas].n_tris < 32768u;
+        // one or two slices per launch: the tail of a few long waves sets the time, and those run faster without the
+        // spills of the 6..8-wave builds (monkey Depth 1: 446 us with the 5-wave build, 475 with the 8-wave one)
+        if (depth <= 2 && ctx->single_identity && stack_sel < 31 && !getenv("RR_DEBUG_STACK")) { stack_sel = 31; stack16 = false; }
+        if (depth <= 2) stack16 = false;
         RR_HIP(launch_render_fused(sc, a, stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream, stack16));
     }
     if (timed) {
