@@ -266,9 +266,10 @@ int  rr_download_blas(rr_context* ctx, uint32_t mesh_id, void* nodes, uint32_t* 
                       void* tris, uint32_t* n_tris);
 
 /* The same hierarchy as the traversal kernels read it: n_nodes*32 B, per node six words holding one slab plane
- * of both children on the BLAS's 16-bit grid (child 0 in the low half, child 1 in the high half; order
- * lox,loy,loz,hix,hiy,hiz), then the two child refs (>= 0: byte offset of an internal node, < 0: leaf ~index).
- * grid_org_cell: origin xyz then cell size xyz (plane = org + q*cell).  Every quantised box contains its fp32 box. */
+ * of both children as IEEE half-precision cell counts q on the BLAS's grid (child 0 in the low half, child 1 in the
+ * high half; order lox,loy,loz,hix,hiy,hiz), then the two child refs (>= 0: byte offset of an internal node, < 0:
+ * leaf ~index).  grid_org_cell: origin xyz (the centre of the bounds) then cell size xyz (plane = org + q*cell).
+ * Every stored box contains its fp32 box. */
 int  rr_download_qnodes(rr_context* ctx, uint32_t mesh_id, void* qnodes, uint32_t* n_nodes, float grid_org_cell[6]);
 
 /* ---- pure host helpers (no device, no context) --------------------------------------------- */

@@ -35,8 +35,8 @@ NODE_DTYPE = np.dtype([("lox", "<f4", 2), ("loy", "<f4", 2), ("loz", "<f4", 2), 
 TRI_DTYPE = np.dtype([("v0", "<f4", 3), ("prim", "<u4"), ("e1", "<f4", 3), ("pad1", "<u4"),
                       ("e2", "<f4", 3), ("pad2", "<u4")])
 assert VERTEX_DTYPE.itemsize == 32 and INSTANCE_DTYPE.itemsize == 64 and RAY_DTYPE.itemsize == 48
-QNODE_DTYPE = np.dtype([("lox", "<u2", 2), ("loy", "<u2", 2), ("loz", "<u2", 2), ("hix", "<u2", 2),
-                        ("hiy", "<u2", 2), ("hiz", "<u2", 2), ("c", "<i4", 2)])
+QNODE_DTYPE = np.dtype([("lox", "<f2", 2), ("loy", "<f2", 2), ("loz", "<f2", 2), ("hix", "<f2", 2),
+                        ("hiy", "<f2", 2), ("hiz", "<f2", 2), ("c", "<i4", 2)])
 assert QNODE_DTYPE.itemsize == 32
 assert HIT_DTYPE.itemsize == 24 and NODE_DTYPE.itemsize == 64 and TRI_DTYPE.itemsize == 48
 

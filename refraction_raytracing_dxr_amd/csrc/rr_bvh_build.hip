@@ -7,6 +7,7 @@
 //   radix-tree hierarchy -> bottom-up box refit with one arrival counter per internal node ->
 //   pack into 64-byte nodes that carry BOTH child boxes, so traversal fetches one record per visit.
 // The same builder makes the TLAS (primitives = instance world boxes).
+#include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include "rr_launch.h"
 
@@ -439,18 +440,19 @@ __global__ __launch_bounds__(256) void k_pack_tris(const float* __restrict__ ver
     nrms[i] = m;
 }
 
-// fp32 node -> traversal node on the 16-bit grid g.  lo planes: floor - 1, hi planes: ceil + 1 (the fp32
-// rounding of (v - org)/cell is below 0.02 cells at 65535), clamped to the grid; child refs optionally rebased
-// into the scene pool.
+// fp32 node -> traversal node with fp16 planes on the grid g; child refs optionally rebased into the scene pool.
+// fp16 planes in cell units around the centre of the grid (|x| <= 32768 < 65504): directed rounding outward, after a
+// guard for the fp32 rounding of (v - org)/cell.  The spacing of fp16 grows with |x| (1 cell below 2048 cells from the
+// centre, 16 cells at the faces of the bounds: 2.4e-4 of the extent), always outward, which is all the box test needs.
 __device__ __forceinline__ uint32_t q_lo(float v, float org, float cell)
 {
-    const float x = floorf((v - org) / cell) - 1.0f;
-    return (uint32_t)fminf(fmaxf(x, 0.0f), 65535.0f);          // NaN/-inf -> 0, +inf -> 65535
+    const float x = (v - org) / cell - 0.05f;
+    return (uint32_t)__half_as_ushort(__float2half_rd(x));
 }
 __device__ __forceinline__ uint32_t q_hi(float v, float org, float cell)
 {
-    const float x = ceilf((v - org) / cell) + 1.0f;
-    return (uint32_t)fmaxf(fminf(x, 65535.0f), 0.0f);
+    const float x = (v - org) / cell + 0.05f;
+    return (uint32_t)__half_as_ushort(__float2half_ru(x));
 }
 __global__ __launch_bounds__(256) void k_quantize_nodes(QNode* __restrict__ dst, const BvhNode* __restrict__ src, uint32_t n, QGrid g,
                                                         uint32_t node_off, uint32_t tri_off)

@@ -240,16 +240,16 @@ int use_device(rr_context* ctx)
     return RR_OK;
 }
 
-// 16-bit grid over a box {lo[3], hi[3]}: 65530 cells span the extent, so ceil+1 of the upper bound stays
-// on the grid; a flat axis gets a tiny positive cell
+// grid over a box {lo[3], hi[3]}: 65530 cells span the extent, counted from the centre (planes are stored as fp16
+// cell counts, |q| <= 32768); a flat axis gets a tiny positive cell
 QGrid make_grid(const float b[6])
 {
     QGrid g;
     for (int k = 0; k < 3; ++k) {
         const float ext = b[3 + k] - b[k];
         const float mag = std::max(std::max(std::fabs(b[k]), std::fabs(b[3 + k])), 1e-30f);
-        g.org[k] = b[k];
         g.cell[k] = std::max(ext, mag * 1e-6f) / 65530.0f;
+        g.org[k] = b[k] + 32765.0f * g.cell[k];      // fp16 planes are signed: the grid origin is the centre of the box
     }
     return g;
 }

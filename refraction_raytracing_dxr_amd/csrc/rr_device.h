@@ -119,7 +119,7 @@ constexpr uint32_t CULL_BACK = 0x10u, CULL_FRONT = 0x20u;
 // gets inv = +-1e20: pad is then huge, so the slab on that axis only rejects origins clearly outside
 // it -- rays lying exactly in a box face stay conservative.
 //
-// Planes come from the 16-bit grid of the BLAS (QGrid): plane = org + q*cell, so
+// Planes are fp16 numbers of cells around the centre of the BLAS bounds (QGrid): plane = org + q*cell, so
 // t = q*(cell*inv) + (org - O)*inv; the extra rounding of cell*inv (<= extent*|inv|*2^-24) is far inside
 // the |inv|*eps_w term (eps_w >= 1e-5 * largest |coordinate| >= 5e-6 * extent).
 struct BoxRay {
@@ -170,7 +170,6 @@ constexpr int TRAV_DONE = (int)0x80000000;     // neither an internal index (>= 
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f splat2(float x) { v2f r = { x, x }; return r; }
 __device__ __forceinline__ v2f mk2(float x, float y) { v2f r = { x, y }; return r; }
-__device__ __forceinline__ v2f unpack2(uint32_t w) { return mk2((float)(w & 0xffffu), (float)(w >> 16)); }
 
 // raw min/max instructions (IEEE minNum/maxNum of their operands; written as asm so that the compiler does not
 // add a canonicalising v_max x,x per operand per trip)
@@ -181,18 +180,22 @@ __device__ __forceinline__ float vmin2(float a, float b) { float r; asm("v_min_f
 
 // slab test of BOTH children of a node.  The ray's direction signs say which plane of each axis is the near
 // one, so six selects on the packed words (both children at once) replace the min/max of the slab test;
-// then twelve u16 -> f32 conversions (SDWA selects the half word) and six v_pk_fma_f32 give the near and far
-// distances of both children, tn0/tn1 are the entry distances.
+// then twelve v_fma_mix_f32 give the near and far distances of both children, tn0/tn1 are the entry distances.
+// one plane word = the fp16 plane coordinates of child 0 (low half) and child 1 (high half), in grid cells; each
+// distance is one v_fma_mix_f32 (the half is widened inside the FMA: no conversion instruction)
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h2v as_h2(uint32_t w) { return __builtin_bit_cast(h2v, w); }
+#define RR_PLANE2(word, inv, k) mk2(fmaf((float)as_h2(word).x, inv, k), fmaf((float)as_h2(word).y, inv, k))
 __device__ __forceinline__ void box2_hit(const BoxRay& r, const NodeQ& n, float tmin, float tmax,
                                          bool& h0, bool& h1, float& tn0, float& tn1)
 {
     const uint32_t lox = n.a.x, loy = n.a.y, loz = n.a.z, hix = n.a.w, hiy = n.b.x, hiz = n.b.y;
-    const v2f nx = __builtin_elementwise_fma(unpack2(r.sx ? hix : lox), splat2(r.inv.x), splat2(r.kn.x));
-    const v2f ny = __builtin_elementwise_fma(unpack2(r.sy ? hiy : loy), splat2(r.inv.y), splat2(r.kn.y));
-    const v2f nz = __builtin_elementwise_fma(unpack2(r.sz ? hiz : loz), splat2(r.inv.z), splat2(r.kn.z));
-    const v2f fx = __builtin_elementwise_fma(unpack2(r.sx ? lox : hix), splat2(r.inv.x), splat2(r.kf.x));
-    const v2f fy = __builtin_elementwise_fma(unpack2(r.sy ? loy : hiy), splat2(r.inv.y), splat2(r.kf.y));
-    const v2f fz = __builtin_elementwise_fma(unpack2(r.sz ? loz : hiz), splat2(r.inv.z), splat2(r.kf.z));
+    const v2f nx = RR_PLANE2(r.sx ? hix : lox, r.inv.x, r.kn.x);
+    const v2f ny = RR_PLANE2(r.sy ? hiy : loy, r.inv.y, r.kn.y);
+    const v2f nz = RR_PLANE2(r.sz ? hiz : loz, r.inv.z, r.kn.z);
+    const v2f fx = RR_PLANE2(r.sx ? lox : hix, r.inv.x, r.kf.x);
+    const v2f fy = RR_PLANE2(r.sy ? loy : hiy, r.inv.y, r.kf.y);
+    const v2f fz = RR_PLANE2(r.sz ? loz : hiz, r.inv.z, r.kf.z);
     tn0 = vmax2(vmax3(nx.x, ny.x, nz.x), tmin);
     tn1 = vmax2(vmax3(nx.y, ny.y, nz.y), tmin);
     const float tf0 = vmin2(vmin3(fx.x, fy.x, fz.x), tmax);

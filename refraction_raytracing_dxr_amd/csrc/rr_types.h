@@ -1,8 +1,8 @@
 // rr_types.h -- records shared by the host side of the C ABI and the gfx950 kernels.
 //
 // HBM layout (all arrays 16-byte aligned, hipMalloc'ed once per mesh / scene):
-//   QNode    32 B  what traversal reads: both child boxes on the 16-bit grid of the BLAS bounds + both child
-//                  refs, TWO 16-byte requests per visit (the render kernel is bound by L1 request rate)
+//   QNode    32 B  what traversal reads: both child boxes as fp16 cell counts on the grid of the BLAS bounds + both
+//                  child refs, TWO 16-byte requests per visit
 //   BvhNode  64 B  the same node in fp32 (builder output, rr_download_blas); QNode is derived from it
 //   TriRec   48 B  v0,e1,e2 in LBVH leaf order, original PrimitiveIndex() in v0.w
 //   NrmRec   48 B  the three vertex normals of the same triangle (ClosestHit, RayTracing.hlsl:83-85)
@@ -24,11 +24,12 @@ struct alignas(16) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 B");
 
-// 16-bit grid over the bounds of one BLAS (object space) or of the scene (TLAS level): plane = org + q*cell.
+// Grid over the bounds of one BLAS (object space) or of the scene (TLAS level): plane = org + q*cell, org the centre
+// of the bounds, 65530 cells across the extent.
 struct QGrid { float org[3]; float cell[3]; };
-// Traversal node.  Every word holds one slab plane of both children: child 0 in the low half, child 1 in the
-// high half, so two conversions feed one v_pk_fma_f32.  lo planes are rounded down, hi planes up (one extra
-// cell each way): the quantised box always contains the fp32 box, which is all the box test needs.
+// Traversal node.  Every word holds one slab plane of both children as fp16 cell counts q: child 0 in the low half,
+// child 1 in the high half (v_fma_mix_f32 reads either half directly).  lo planes are rounded down, hi planes up:
+// the stored box always contains the fp32 box, which is all the box test needs.
 struct alignas(16) QNode {
     uint32_t lox, loy, loz, hix;
     uint32_t hiy, hiz;

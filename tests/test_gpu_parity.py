@@ -248,9 +248,10 @@ def test_builds_are_deterministic(gpu):
 
 @pytest.mark.parametrize("name", ["cube.obj", "monkey.obj", "ott.obj"])
 def test_quantised_nodes_contain_the_fp32_boxes(gpu, name):
-    """Traversal reads 32-byte nodes on a 16-bit grid of the mesh bounds.  The box test only has to be conservative:
-    every quantised child box must contain its fp32 box (evaluated in float64 from the same float32 grid the
-    kernels use), by at most three cells; child refs are the same tree with internal refs as byte offsets."""
+    """Traversal reads 32-byte nodes whose planes are fp16 cell counts on a grid over the mesh bounds.  The box test
+    only has to be conservative: every stored child box must contain its fp32 box (evaluated in float64 from the same
+    float32 grid the kernels use), by no more than the fp16 spacing there (<= 16 cells at the faces of the bounds) plus
+    the guard cell; child refs are the same tree with internal refs as byte offsets."""
     m = load(name)
     mid = gpu.upload_mesh(m.verts, m.indices)
     gpu.build_blas(mid)
@@ -263,13 +264,15 @@ def test_quantised_nodes_contain_the_fp32_boxes(gpu, name):
         qhi = org[ax] + q[hi].astype(np.float64) * cell[ax]
         flo, fhi = nodes[lo].astype(np.float64), nodes[hi].astype(np.float64)
         real = flo <= fhi                                      # (a one-triangle mesh has an empty second child)
+        assert np.all(np.abs(q[lo][real].astype(np.float64)) <= 32768) and np.all(np.abs(q[hi][real].astype(np.float64)) <= 32768)
         assert np.all(qlo[real] <= flo[real]) and np.all(qhi[real] >= fhi[real])
-        assert np.all(flo[real] - qlo[real] <= 3 * cell[ax]) and np.all(qhi[real] - fhi[real] <= 3 * cell[ax])
+        assert np.all(flo[real] - qlo[real] <= 18 * cell[ax]) and np.all(qhi[real] - fhi[real] <= 18 * cell[ax])
     c, qc = nodes["c"], q["c"]
     assert np.array_equal(qc[c < 0], c[c < 0]) and np.array_equal(qc[c >= 0], c[c >= 0] * 32)
-    # the grid spans the mesh bounds
+    # the grid spans the mesh bounds, origin at their centre
     P = m.verts["position"][m.indices].astype(np.float64)
-    assert np.all(org <= P.min(0)) and np.all(org + 65535 * cell >= P.max(0))
+    assert np.all(org - 32768 * cell <= P.min(0)) and np.all(org + 32768 * cell >= P.max(0))
+    assert np.all(np.abs(org - (P.min(0) + P.max(0)) / 2) <= 8 * cell + 1e-6 * np.abs(org))
 
 
 def test_fast_build_and_fast_trace_hierarchies_render_the_same_frame(gpu):
