@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 def algorithmic_bytes(st):
     """Bytes the traversal/shading must touch (DESIGN.md 'Algorithmic bytes'), priced with the record sizes the
-    kernel really reads: 32 B per internal node visit (QNode: both child boxes on a 16-bit grid + child refs),
+    kernel really reads: 32 B per internal node visit (QNode: both child boxes as fp16 cell counts + child refs),
     48 B per triangle test, 36 B of vertex normals per shaded hit, 12 B env texel per miss, 4 B RGBA8 per
     pixel.  (SURVEY 8d prices a node at 64 B (fp32 boxes) and adds a ray queue and a float accumulator the
     fused kernel does not have; that figure is reported next to this one as survey_formula_bytes_per_ray.)"""

@@ -60,7 +60,7 @@ struct MeshRes {
     uint32_t* d_idx = nullptr;
     uint32_t  n_verts = 0, n_idx = 0, n_tris = 0;
     BvhNode*  nodes = nullptr;       // fp32 hierarchy (builder output, rr_download_blas)
-    QNode*    qnodes = nullptr;      // what traversal reads: the same nodes on the 16-bit grid of the bounds
+    QNode*    qnodes = nullptr;      // what traversal reads: the same nodes with fp16 planes on the grid of the bounds
     QGrid     grid = { { 0, 0, 0 }, { 1, 1, 1 } };
     TriRec*   tris = nullptr;
     NrmRec*   nrms = nullptr;

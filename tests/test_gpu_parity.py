@@ -168,7 +168,7 @@ def _soup(kind, n, seed):
 @pytest.mark.parametrize("fast_build", [False, True])
 def test_trace_rays_awkward_geometry_vs_brute_force(gpu, kind, n, fast_build):
     """flat, far-away, wildly mixed-size / degenerate and collinear triangle soups: closest hit through the GPU
-    hierarchy (both builders, boxes on the 16-bit grid) == the oracle's brute force, bit for bit"""
+    hierarchy (both builders, fp16 boxes on the grid of the bounds) == the oracle's brute force, bit for bit"""
     verts, idx = _soup(kind, n, seed=n + len(kind))
     mid = gpu.upload_mesh(verts, idx)
     gpu.build_blas(mid, fast_build=fast_build)
