@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--no-subdiv", action="store_true",
                     help="skip the second figure (15 472-triangle monkey); profiling runs use this so that every "
                          "k_render_fused launch in the trace is a launch of the headline workload")
+    ap.add_argument("--rotate-root", action="store_true",
+                    help="N>1: gather batch b to rank b %% N instead of rank 0 (frames end up spread over the ranks; "
+                         "no single GPU takes in every frame).  Off by default: the reference presents from one device")
     ap.add_argument("--frames-per-dispatch", type=int, default=64,
                     help="depth slices per launch (DispatchRays(W,H,Depth)); N>1: also frames per RCCL gather")
     args = ap.parse_args()
@@ -160,7 +163,8 @@ def main():
         # a rank's share of a launch has 1/world of the blocks: keep launches long enough for their tails not to show
         # (tools/exp_lanes.py, world 8: 113 us/frame-equivalent at 64 frames per launch, 108 at 256)
         Fn = args.frames_per_dispatch * max(1, min(world // 2, 4))
-        sf = rr.dist.ShardedFrames(r, W, H, rank, world, torch.device("cuda", local_rank), Fn, always_collective=force_sharded)
+        sf = rr.dist.ShardedFrames(r, W, H, rank, world, torch.device("cuda", local_rank), Fn, always_collective=force_sharded,
+                                   rotate_root=args.rotate_root)
         sf.render_orbit(Wm, angle=0.01, params=params)
         barrier()
         t0 = time.perf_counter()
@@ -262,7 +266,7 @@ def main():
             "config": {"workload": "monkey.obj (967 tri) 1920x1080, 8 refraction / 2 reflection bounces, ior 1.3, "
                                    "orbit angle 0.01*(k+1), seeded procedural 2048x1024 RGB32F env map",
                        "rays_per_frame": round(total_rays / K, 1),
-                       "parallelism": "tiles32x32-roundrobin-x%d" % world,
+                       "parallelism": "tiles32x32-roundrobin-x%d%s" % (world, "-rotating-root" if args.rotate_root and world > 1 else ""),
                        "frames_per_dispatch": F if world == 1 else F * max(1, min(world // 2, 4))},
             "device_region_ms_per_step": round(region_ms / K, 5) if region_ms is not None else None,
             "roofline": roofline,

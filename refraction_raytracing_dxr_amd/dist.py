@@ -98,9 +98,13 @@ class ShardedFrames:
     RING = 3
     LANES = 2
 
-    def __init__(self, renderer, width, height, rank, world, device, frames_per_gather=8, rgb8=True, always_collective=False):
+    def __init__(self, renderer, width, height, rank, world, device, frames_per_gather=8, rgb8=True, always_collective=False,
+                 rotate_root=False):
         """rgb8: tiles travel as 3 bytes per pixel (a quarter less into rank 0, whose xGMI ingest is what bounds the
-        8-GPU frame rate); rank 0 restores RGBA8 while de-interleaving."""
+        8-GPU frame rate); rank 0 restores RGBA8 while de-interleaving.
+        rotate_root: batch b is gathered to rank b % world instead of rank 0, so the assembled frames end up spread
+        over the ranks (a render farm feeding one consumer per GPU) and no single GPU has to take in every frame: the
+        ingest per link drops by a factor world.  Default off: the reference presents from one device."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -111,41 +115,46 @@ class ShardedFrames:
         self.max_tiles = max_local_tiles(width, height, world)
         self.frame_bytes = self.max_tiles * (TILE_BYTES_RGB8 if self.rgb8 else TILE_BYTES)
         renderer.set_tile_partition(rank, world)
+        self.rotate_root = bool(rotate_root) and world > 1
+        is_root = rank == 0 or self.rotate_root
         self.send = [torch.zeros(self.F * self.frame_bytes, dtype=torch.uint8, device=device) for _ in range(self.RING)]
         self.recv = [torch.zeros(world * self.F * self.frame_bytes, dtype=torch.uint8, device=device)
-                     for _ in range(self.RING)] if rank == 0 else None
-        # the most recent batch of assembled frames (rank 0)
-        self.frames = torch.zeros(self.F * height * width * 4, dtype=torch.uint8, device=device) if rank == 0 else None
+                     for _ in range(self.RING)] if is_root else None
+        # the most recent batch of assembled frames (on the rank that was its root)
+        self.frames = torch.zeros(self.F * height * width * 4, dtype=torch.uint8, device=device) if is_root else None
         self.last_batch = 0
         self._on_frames = None
         self._via_host = world > 1 and dist.get_backend() == "gloo"     # test rigs without RCCL: stage through host
         self._always_collective = bool(always_collective)               # world == 1: still go through dist.gather (tests)
 
-    def _gather(self, slot, nf):
+    def _root(self, batch):
+        return batch % self.world if self.rotate_root else 0
+
+    def _gather(self, slot, nf, dst=0):
         n = nf * self.frame_bytes
         send = self.send[slot][:n]
         if self.world == 1 and not self._always_collective:
             self.recv[slot][:n].copy_(send)
             return None
         chunks = None
-        if self.rank == 0:
+        if self.rank == dst:
             chunks = [self.recv[slot][r * self.F * self.frame_bytes: r * self.F * self.frame_bytes + n]
                       for r in range(self.world)]
         if self._via_host:
             hs = send.cpu()
-            hc = [self.torch.empty_like(hs) for _ in range(self.world)] if self.rank == 0 else None
-            self.dist.gather(hs, hc, dst=0)
-            if self.rank == 0:
+            hc = [self.torch.empty_like(hs) for _ in range(self.world)] if self.rank == dst else None
+            self.dist.gather(hs, hc, dst=dst)
+            if self.rank == dst:
                 for c, h in zip(chunks, hc):
                     c.copy_(h)
             return None
-        return self.dist.gather(send, chunks, dst=0, async_op=True)
+        return self.dist.gather(send, chunks, dst=dst, async_op=True)
 
     def _finish(self, pending):
-        slot, nf, work = pending
+        slot, nf, work, dst = pending
         if work is not None:
             work.wait()                     # current stream waits for RCCL's stream; the host does not
-        if self.rank == 0:
+        if self.rank == dst:
             self.r.assemble_frames(self.recv[slot].data_ptr(), self.world, self.F * self.frame_bytes, self.frame_bytes,
                                    nf, self.width, self.height, self.frames.data_ptr(), self.height * self.width * 4,
                                    rgb8=self.rgb8)
@@ -155,14 +164,15 @@ class ShardedFrames:
 
     def render_orbit(self, n_frames, angle=0.01, angle_step=0.01, params=None, on_frames=None):
         """Renders, gathers and assembles n_frames; returns the rays this rank traced (blocks at the end
-        to read the counter).  on_frames(uint8 [nf, h, w, 4] device view), rank 0 only, is called once per
-        assembled batch in frame order; the view is overwritten by the next batch."""
+        to read the counter).  on_frames(uint8 [nf, h, w, 4] device view) is called on the root of each batch (rank 0,
+        or rank b % world with rotate_root) once per assembled batch, in frame order on that rank; the view is
+        overwritten by that rank's next batch."""
         self._on_frames = on_frames
         from .host import default_params
         from ._capi import DISPATCH_KEEP_COUNTERS, DISPATCH_TILES_RGB8
         base = params if params is not None else default_params()
-        rendered = None        # (slot, nf, lane): launched, not yet joined / gathered
-        gathering = None       # (slot, nf, work): gather in flight
+        rendered = None        # (slot, nf, lane, root): launched, not yet joined / gathered
+        gathering = None       # (slot, nf, work, root): gather in flight
         done = 0
         b = 0
         while done < n_frames:
@@ -180,7 +190,7 @@ class ShardedFrames:
                                                 lane=lane)
             if rendered is not None:
                 rendered, gathering = None, self._advance(rendered, gathering)
-            rendered = (slot, nf, lane)
+            rendered = (slot, nf, lane, self._root(b))
             done += nf
             b += 1
         if rendered is not None:
@@ -191,15 +201,15 @@ class ShardedFrames:
 
     def _advance(self, rendered, gathering):
         """join + gather the batch that was launched before the newest one; finish the one before that"""
-        slot, nf, lane = rendered
+        slot, nf, lane, dst = rendered
         self.r.lane_join(lane)
-        work = self._gather(slot, nf)
+        work = self._gather(slot, nf, dst)
         if gathering is not None:
             self._finish(gathering)
-        return (slot, nf, work)
+        return (slot, nf, work, dst)
 
     def frames_host(self):
-        """rank 0: the last batch as uint8 [n, h, w, 4]"""
-        assert self.rank == 0
+        """the last batch assembled on this rank as uint8 [n, h, w, 4]"""
+        assert self.frames is not None
         self.torch.cuda.synchronize()
         return self.frames.view(self.F, self.height, self.width, 4)[:self.last_batch].cpu().numpy()

@@ -773,6 +773,58 @@ def test_sharded_frames_pipeline(tmp_path, world, backend, rgb8, W):
     assert ok[0] == 1, ok
 
 
+def _rotating_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = load("monkey.obj")
+    r = rr.Renderer(0)
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
+    r.load_scene(m.verts, m.indices, procedural_env(128, 64, seed=21))
+    W, H, K, F = 256, 130, 11, 2                   # batches 0..5: even ones end on rank 0, odd ones on rank 1
+    sf = rr.dist.ShardedFrames(r, W, H, rank, world, torch.device("cuda", 0), frames_per_gather=F, rotate_root=True)
+    seen = []
+    sf.render_orbit(K, angle=0.01, params=rr.default_params(max_refract=8), on_frames=lambda fr: seen.append(fr.clone()))
+    mine = torch.cat(seen).cpu().numpy()
+    r.set_tile_partition(0, 1)
+    a = np.float32(0.01)
+    frames = []
+    for k in range(K):
+        r.set_camera(rr.camera_orbit(a))
+        r.dispatch_rays(W, H, rr.default_params(max_refract=8))
+        frames.append(r.read_frame().copy())
+        a = np.float32(a + np.float32(0.01))
+    expect = [k for k in range(K) if (k // F) % world == rank]
+    ok = len(mine) == len(expect) and all(np.array_equal(mine[i], frames[k]) for i, k in enumerate(expect))
+    np.save(os.path.join(out_dir, "rot%d.npy" % rank), np.array([int(ok), len(mine), len(expect)]))
+    dist.barrier()
+    r.close()
+    dist.destroy_process_group()
+
+
+def test_sharded_frames_rotating_root(tmp_path):
+    """rotate_root: batch b is gathered to and assembled on rank b % world; every rank ends up with exactly its
+    batches, bit-identical to single-GPU frames (two processes on the one card, gloo)."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_rotating_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    for r in range(2):
+        ok = np.load(tmp_path / ("rot%d.npy" % r))
+        assert ok[0] == 1 and ok[1] == ok[2] > 0, ok
+
+
 # ------------------------------------------------------------------------------- BASELINE configs 4 and 5
 def _xf(tx, ty, tz, s=1.0):
     m = np.eye(4, dtype=np.float32)[:3] * np.float32(s)
