@@ -616,10 +616,18 @@ def test_refraction_demo_mirror(tmp_path, env_png):
 
 
 # ------------------------------------------------------------------------------- depth slices
-def test_batched_dispatch_equals_single_dispatches(gpu):
+@pytest.mark.parametrize("name", ["monkey.obj", "ott.obj", "sub2"])
+def test_batched_dispatch_equals_single_dispatches(gpu, name):
     """DispatchRays(W,H,Depth): every slice is byte-identical to a Depth=1 dispatch with the same constants,
-    and the ray counter is the sum."""
-    m = load("monkey.obj")
+    and the ray counter is the sum.  A Depth-1 launch runs the 5-waves-per-SIMD build; the batch runs the build
+    for the tree's depth class: 8 waves with 32-bit stack entries (monkey.obj, 18 levels), 16-bit entries (ott.obj,
+    31 levels; the subdivided monkey, 24) -- all three must agree with the oracle-checked single dispatches."""
+    if name == "sub2":
+        from refraction_raytracing_dxr_amd.synth import subdivide
+        m = rr.Mesh()
+        m.verts, m.indices = subdivide(load("monkey.obj").verts, 2)
+    else:
+        m = load(name)
     env = procedural_env(128, 64, seed=13)
     gpu_scene(gpu, [m], env)
     gpu.set_tile_partition(0, 1)

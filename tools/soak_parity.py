@@ -25,11 +25,17 @@ for k in range(n):
     r.load_scene(m.verts, m.indices, env)
     sc = rr.camera_orbit(ang)
     r.set_camera(sc)
-    r.dispatch_rays(W, H, rr.default_params(flags=rr.DISPATCH_FLOAT_OUTPUT, **kw))
-    rgba, f32 = r.read_frame(want_float=True)
+    if k % 2:       # every other frame goes through a Depth-3 batch: the high-occupancy builds (8 waves, 16-bit stacks)
+        r.dispatch_rays_batch(W, H, [rr.camera_orbit(ang + 1.0), sc, rr.camera_orbit(ang + 2.0)], rr.default_params(flags=rr.DISPATCH_FLOAT_OUTPUT, **kw))
+        rgba, f32 = r.read_frame(want_float=True, slice=1)
+        rays_gpu = None
+    else:
+        r.dispatch_rays(W, H, rr.default_params(flags=rr.DISPATCH_FLOAT_OUTPUT, **kw))
+        rgba, f32 = r.read_frame(want_float=True)
+        rays_gpu = r.stats().rays
     s = O.Scene(); s.add_mesh(m.verts, m.indices); s.set_envmap(env)
     pw = s.render(np.array(sc.proj_inv, np.float32), np.array(sc.camera_loc, np.float32), W, H, O.default_params(use_bvh=1, accum_mode=1, **kw))
-    ok = np.array_equal(f32[..., :3].view(np.uint32), pw["rgb"].view(np.uint32)) and np.array_equal(rgba, pw["rgba8"]) and r.stats().rays == pw["stats"].rays
+    ok = np.array_equal(f32[..., :3].view(np.uint32), pw["rgb"].view(np.uint32)) and np.array_equal(rgba, pw["rgba8"]) and (rays_gpu is None or rays_gpu == pw["stats"].rays)
     if not ok:
         bad += 1
         print("MISMATCH", name, W, H, ang, kw, int((rgba != pw["rgba8"]).any(-1).sum()), "pixels", flush=True)
