@@ -260,6 +260,11 @@ int  rr_host_unregister(rr_context* ctx, void* p);
  * Stands for RayTracing.hlsl:60,106,121 in isolation; used by the parity tests. */
 int  rr_trace_rays(rr_context* ctx, const rr_ray* rays, uint32_t n, rr_hit* hits);
 
+/* Miss on caller-supplied ray directions (host arrays of n x 3 floats in, n x 3 floats out): the equirectangular lookup
+ * of RayTracing.hlsl:127-137 in isolation -- atan2 / acos, the division by the literal 3.14159, the float-to-uint texel
+ * address and the zero returned outside the texture (reached at atan2 = pi and at r.y = -1); used by the parity tests. */
+int  rr_env_lookup(rr_context* ctx, const float* dirs, uint32_t n, float* rgb);
+
 /* Introspection for tests: copies the packed BLAS of a mesh to host.  nodes: n_nodes*64 B
  * (two child boxes + two child refs), tris: n_tris*48 B (v0,e1,e2 with prim id in v0.w). */
 int  rr_download_blas(rr_context* ctx, uint32_t mesh_id, void* nodes, uint32_t* n_nodes,

@@ -104,6 +104,7 @@ SYMBOLS = {
     "rr_timing_end": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "rr_kernel_time": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "rr_trace_rays": (C.c_int, [_P, _P, C.c_uint32, _P]),
+    "rr_env_lookup": (C.c_int, [_P, _P, C.c_uint32, _P]),
     "rr_download_blas": (C.c_int, [_P, C.c_uint32, _P, C.POINTER(C.c_uint32), _P, C.POINTER(C.c_uint32)]),
     "rr_host_register": (C.c_int, [_P, _P, C.c_size_t]),
     "rr_host_unregister": (C.c_int, [_P, _P]),

@@ -105,6 +105,10 @@ struct rr_context {
     bool tlas_built = false;
     bool single_identity = false;
     float scene_scale = 1.0f;
+    float scene_bounds[6] = { 0, 0, 0, 0, 0, 0 };   // world-space box of the whole scene (the TLAS root)
+
+    float*   d_screen = nullptr;     // GenerateCameraRay's screen coordinates for frames of screen_w x screen_h: sx[W], sy[H]
+    uint32_t screen_w = 0, screen_h = 0;
 
     rr_scene_constants cam;
     bool cam_set = false;
@@ -135,6 +139,16 @@ struct rr_context {
     bool      last_stats = false;
 
     CounterBlock* d_cnt = nullptr;
+    uint32_t* d_park[MAX_LANES + 1] = {};   // k_render_lds: parked reflected rays, one slab per stream slot like the tickets
+    size_t    park_bytes[MAX_LANES + 1] = {};
+    uint32_t* d_tickets = nullptr;   // k_render_lds ticket words: one block per stream a launch can be on (lanes, then the context's stream)
+
+    // diagnostics switches, read once at rr_create (never needed for correct results)
+    int  dbg_kernel = 0;             // RR_DEBUG_KERNEL: 0 default, 1 "fused" (never the LDS kernel), 2 "async", 3 "wavefront", 4 "lds" (at every depth)
+    int  dbg_stack = 0;              // RR_DEBUG_STACK
+    int  dbg_ticket_blocks = 0;      // RR_DEBUG_TICKET: 1 = k_render_lds treats the whole frame as the mesh rectangle, 2 = no rectangle
+    int  dbg_shape = 0;              // RR_DEBUG_SHAPE: first k_render_lds workgroup shape to consider (rr_launch.h)
+    std::string dbg_diag;            // RR_DEBUG_DIAG: file that receives per-wave diagnostics of Depth-1 dispatches
 
     // timing
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -319,13 +333,22 @@ int rr_create(int device_ordinal, rr_context** out)
     ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipSetDevice(device_ordinal) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(&ctx->d_cnt, sizeof(CounterBlock)) != hipSuccess) {
+        hipMalloc(&ctx->d_cnt, sizeof(CounterBlock)) != hipSuccess ||
+        hipMalloc(&ctx->d_tickets, (rr_context::MAX_LANES + 1) * LDS_TICKET_WORDS * sizeof(uint32_t)) != hipSuccess) {
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+        dfree(ctx->d_cnt);
         delete ctx;
         return RR_ERR_DEVICE;
     }
     ctx->stream = ctx->own_stream;
     (void)hipMemsetAsync(ctx->d_cnt, 0, sizeof(CounterBlock), ctx->stream);
+    (void)hipMemsetAsync(ctx->d_tickets, 0, (rr_context::MAX_LANES + 1) * LDS_TICKET_WORDS * sizeof(uint32_t), ctx->stream);   // the kernel leaves them zero
+    if (const char* e = getenv("RR_DEBUG_KERNEL"))
+        ctx->dbg_kernel = !strcmp(e, "fused") ? 1 : !strcmp(e, "async") ? 2 : !strcmp(e, "wavefront") ? 3 : !strcmp(e, "lds") ? 4 : 0;
+    if (const char* e = getenv("RR_DEBUG_STACK")) ctx->dbg_stack = atoi(e);
+    if (const char* e = getenv("RR_DEBUG_TICKET")) ctx->dbg_ticket_blocks = atoi(e);
+    if (const char* e = getenv("RR_DEBUG_SHAPE")) ctx->dbg_shape = atoi(e);
+    if (const char* e = getenv("RR_DEBUG_DIAG")) ctx->dbg_diag = e;
     *out = ctx;
     return RR_OK;
 }
@@ -346,7 +369,8 @@ int rr_destroy(rr_context* ctx)
     for (MeshRes& m : ctx->meshes) { dfree(m.d_verts); dfree(m.d_idx); dfree(m.nodes); dfree(m.qnodes); dfree(m.tris); dfree(m.nrms); }
     dfree(ctx->d_env); dfree(ctx->d_insts); dfree(ctx->d_pool_nodes); dfree(ctx->d_pool_qnodes); dfree(ctx->d_pool_tris); dfree(ctx->d_pool_nrms); dfree(ctx->d_rgba8); dfree(ctx->d_f32);
     dfree(ctx->wf.q[0]); dfree(ctx->wf.q[1]); dfree(ctx->wf.slots); dfree(ctx->wf.hit_list); dfree(ctx->wf.counts);
-    dfree(ctx->d_assembled); dfree(ctx->d_cnt); dfree(ctx->d_rays); dfree(ctx->d_hits); dfree(ctx->d_cams);
+    dfree(ctx->d_assembled); dfree(ctx->d_cnt); dfree(ctx->d_tickets); dfree(ctx->d_screen);
+    for (uint32_t l = 0; l <= rr_context::MAX_LANES; ++l) dfree(ctx->d_park[l]); dfree(ctx->d_rays); dfree(ctx->d_hits); dfree(ctx->d_cams);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
@@ -582,6 +606,7 @@ int rr_build_tlas(rr_context* ctx, const rr_instance_desc* instances, uint32_t n
                 sb[3] = std::max(sb[3], root.hix[k]); sb[4] = std::max(sb[4], root.hiy[k]); sb[5] = std::max(sb[5], root.hiz[k]);
             }
             ctx->scene_grid = make_grid(sb);
+            memcpy(ctx->scene_bounds, sb, sizeof sb);
             e = launch_quantize_nodes(ctx->d_pool_qnodes, ctx->d_pool_nodes, n_tlas, ctx->scene_grid, 0, 0, ctx->stream);
         }
         for (size_t mi = 0; mi < ctx->meshes.size() && e == hipSuccess; ++mi) {
@@ -687,10 +712,52 @@ int ensure_lane(rr_context* ctx, uint32_t lane)
     return RR_OK;
 }
 
-// out_slot: which of the frames_in_flight output regions of the internal frame buffer this dispatch writes
+// Screen rectangle (pixels, aligned outward to 8x8 blocks, 8 pixels of margin) that contains the projection of the box
+// {lo[3], hi[3]} for every one of the n slices' constants.  GenerateCameraRay (RayTracing.hlsl:27-40) sends pixel s to
+// the direction A * (sx, sy, 1) with A = columns 0, 1, 3 of proj_inv's upper three rows, so a point X is seen at
+// (a/c, b/c) where A * (a, b, c) = X - camera_loc, provided c > 0.  A corner at or behind the camera plane makes the
+// rectangle the whole frame.  Only an ordering hint for k_render_lds: pixels outside it are rendered all the same.
+void mesh_screen_rect(const float box[6], const rr_scene_constants* cams, uint32_t n, uint32_t W, uint32_t H, uint32_t r[4])
+{
+    double x0 = 1e30, y0 = 1e30, x1 = -1e30, y1 = -1e30;
+    bool all = cams == nullptr;
+    for (uint32_t f = 0; f < n && !all; ++f) {
+        const float* M = cams[f].proj_inv;
+        const double A[3][3] = { { M[0], M[1], M[3] }, { M[4], M[5], M[7] }, { M[8], M[9], M[11] } };
+        const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                           A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+        if (!(std::fabs(det) > 1e-30)) { all = true; break; }
+        for (int c = 0; c < 8 && !all; ++c) {
+            const double d[3] = { (double)((c & 1) ? box[3] : box[0]) - cams[f].camera_loc[0],
+                                  (double)((c & 2) ? box[4] : box[1]) - cams[f].camera_loc[1],
+                                  (double)((c & 4) ? box[5] : box[2]) - cams[f].camera_loc[2] };
+            // Cramer's rule
+            const double da = d[0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (d[1] * A[2][2] - A[1][2] * d[2]) +
+                              A[0][2] * (d[1] * A[2][1] - A[1][1] * d[2]);
+            const double db = A[0][0] * (d[1] * A[2][2] - A[1][2] * d[2]) - d[0] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                              A[0][2] * (A[1][0] * d[2] - d[1] * A[2][0]);
+            const double dc = A[0][0] * (A[1][1] * d[2] - d[1] * A[2][1]) - A[0][1] * (A[1][0] * d[2] - d[1] * A[2][0]) +
+                              d[0] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+            const double cc = dc / det;
+            if (!(cc > 1e-6)) { all = true; break; }
+            const double sx = da / det / cc, sy = db / det / cc;
+            const double px = (sx + 1.0) * 0.5 * W - 0.5, py = (1.0 - sy) * 0.5 * H - 0.5;
+            if (!(std::fabs(px) < 1e9 && std::fabs(py) < 1e9)) { all = true; break; }
+            x0 = std::min(x0, px); x1 = std::max(x1, px); y0 = std::min(y0, py); y1 = std::max(y1, py);
+        }
+    }
+    const uint32_t W8 = (W + 7u) & ~7u, H8 = (H + 7u) & ~7u;
+    if (all) { r[0] = 0; r[1] = 0; r[2] = W8; r[3] = H8; return; }
+    auto lo8 = [](double v, uint32_t lim) { const double q = std::floor((v - 8.0) / 8.0) * 8.0; return q <= 0.0 ? 0u : q >= lim ? lim : (uint32_t)q; };
+    auto hi8 = [](double v, uint32_t lim) { const double q = std::ceil((v + 9.0) / 8.0) * 8.0; return q <= 0.0 ? 0u : q >= lim ? lim : (uint32_t)q; };
+    r[0] = lo8(x0, W8); r[1] = lo8(y0, H8); r[2] = hi8(x1, W8); r[3] = hi8(y1, H8);
+}
+
+// out_slot: which of the frames_in_flight output regions of the internal frame buffer this dispatch writes;
+// h_cams: host copy of the depth slices' constants (may be null: no ordering hint)
 int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t depth, const CamDev* d_cams,
-                  const rr_dispatch_params& p, uint32_t* ext_tiles, size_t ext_stride_elems, bool keep_counters,
-                  uint32_t out_slot = 0, uint32_t out_slot_depth = 0)
+                  const rr_scene_constants* h_cams, const rr_dispatch_params& p, uint32_t* ext_tiles, size_t ext_stride_elems,
+                  bool keep_counters, uint32_t out_slot = 0, uint32_t out_slot_depth = 0)
 {
     if (width == 0 || height == 0 || width > 32768 || height > 32768 || depth == 0 || depth > 65535)
         return fail(ctx, RR_ERR_INVALID_ARGUMENT, "dispatch: bad frame size or depth");
@@ -714,10 +781,25 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     if (!ext_tiles)
         if (int r = ensure_frame_buffers(ctx, out_base + slice_elems * depth, want_f32)) return r;
 
+    if (width != ctx->screen_w || height != ctx->screen_h) {     // new frame size: new tables (nothing in flight may still read the old ones)
+        RR_HIP(hipDeviceSynchronize());
+        dfree(ctx->d_screen);
+        ctx->screen_w = ctx->screen_h = 0;
+        RR_HIP(hipMalloc(&ctx->d_screen, ((size_t)width + height) * sizeof(float)));
+        RR_HIP(launch_screen_tables(ctx->d_screen, width, height, ctx->stream));
+        RR_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->screen_w = width; ctx->screen_h = height;
+    }
     SceneDev sc;
     fill_scene(ctx, sc);
     DispatchDev a;
     memset(&a, 0, sizeof a);
+    a.sx = ctx->d_screen; a.sy = ctx->d_screen + width;
+    {   // where the scene can be seen at all in these slices
+        uint32_t hr[4];
+        mesh_screen_rect(ctx->scene_bounds, h_cams, depth, width, height, hr);
+        a.hx0 = hr[0]; a.hy0 = hr[1]; a.hx1 = hr[2]; a.hy1 = hr[3];
+    }
     a.cams = d_cams;
     a.n_frames = depth;
     a.blocks_per_frame = ((local + 7u) & ~7u) * 4u;
@@ -737,8 +819,13 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     a.error_flag = &ctx->d_cnt->error;
     a.diag = nullptr;
     unsigned long long* d_diag = nullptr;
-    const char* diag_path = getenv("RR_DEBUG_DIAG");
-    if (diag_path && ctx->single_identity && depth == 1) { RR_HIP(hipMalloc(&d_diag, (size_t)a.n_blocks * 4 * 32)); a.diag = d_diag; }
+    const char* diag_path = ctx->dbg_diag.empty() ? nullptr : ctx->dbg_diag.c_str();
+    const size_t diag_waves = std::max<size_t>((size_t)a.n_blocks * 4, (size_t)ctx->n_cus * 32);
+    if (diag_path && ctx->single_identity && (depth == 1 || ctx->dbg_kernel == 4)) {
+        RR_HIP(hipMalloc(&d_diag, diag_waves * 32));
+        RR_HIP(hipMemsetAsync(d_diag, 0, diag_waves * 32, ctx->stream));
+        a.diag = d_diag;
+    }
 
     const bool stats = (p.flags & RR_DISPATCH_COLLECT_STATS) != 0;
     const uint32_t need = scene_stack_need(ctx);
@@ -759,8 +846,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         RR_HIP(hipEventRecord(ctx->kev[(size_t)ctx->kev_used * 2], ctx->stream));
     }
     int stack_sel = need <= 19 ? 19 : need <= 22 ? 22 : need <= 26 ? 26 : need <= 31 ? 31 : need <= 39 ? 39 : 64;     // rr_render.hip: sizes that fill the LDS with 6 / 5 / 4 / 2 workgroups
-    static const bool want_wavefront = [] { const char* e = getenv("RR_DEBUG_KERNEL"); return e && !strcmp(e, "wavefront"); }();
-    const bool wavefront = want_wavefront && ctx->single_identity && !compact && !want_f32 && !stats && p.max_reflect <= 2 && p.max_refract < 62;
+    const bool wavefront = ctx->dbg_kernel == 3 && ctx->single_identity && !compact && !want_f32 && !stats && p.max_reflect <= 2 && p.max_refract < 62;
     if (wavefront) {        // experiment: queue-per-bounce kernels; buffers sized for this dispatch
         const size_t px = (size_t)width * height * depth;
         if (px > ctx->wf_pixels) {
@@ -776,24 +862,65 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
             ctx->wf_pixels = px;
         }
     }
-    if (const char* ov = getenv("RR_DEBUG_STACK")) { const int v = atoi(ov); if (v >= (int)need) stack_sel = v; }   // experiments only; never below the tree depth (the kernels do not check)
+    if (ctx->dbg_stack >= (int)need) stack_sel = ctx->dbg_stack;   // experiments only; never below the tree depth (the kernels do not check)
+    // the reference's scene with a node array small enough for LDS (its own meshes up to shell.obj): persistent workgroups,
+    // nodes read from LDS
+    const MeshRes* m0 = ctx->single_identity ? &ctx->meshes[(size_t)ctx->inst_host[0].blas] : nullptr;
+    const uint32_t node_bytes = m0 ? (m0->n_tris > 1 ? m0->n_tris - 1 : 1) * (uint32_t)sizeof(QNode) : 0;
+    // Worth it for launches of many slices (sphere.obj / shell.obj Depth 64: 6-7 % faster than the L1-fed kernel, whose
+    // texture addresser is 83 % busy; monkey.obj the same): a launch of few slices ends on its most expensive blocks, and
+    // there the hardware's own workgroup dispatch starts them earlier than any ticket order tried.  RR_DEBUG_KERNEL=lds
+    // forces it at every depth.
+    const bool lds_kernel = m0 && (ctx->dbg_kernel == 4 || (ctx->dbg_kernel == 0 && depth >= 32)) && ctx->dbg_stack == 0 && m0->n_tris < 32768u && 
+                            lds_kernel_shape(node_bytes, need + 1, nullptr, ctx->dbg_shape) >= 0;
     if (wavefront) RR_HIP(launch_render_wavefront(sc, a, ctx->wf, stack_sel, ctx->stream));
-    else {
+    else if (lds_kernel) {
+        LdsDispatch q;
+        memset(&q, 0, sizeof q);
+        uint32_t slot = rr_context::MAX_LANES;          // launches on one stream are ordered: one ticket block per stream
+        for (uint32_t l = 0; l < rr_context::MAX_LANES; ++l) if (ctx->lane_stream[l] && ctx->stream == ctx->lane_stream[l]) slot = l;
+        q.tickets = ctx->d_tickets + (size_t)slot * LDS_TICKET_WORDS;
+        q.park_slots = p.max_reflect <= 2 ? 2u : 8u;
+        const size_t park_need = (size_t)ctx->n_cus * 32 * q.park_slots * 8 * 64 * sizeof(uint32_t);     // at most 32 waves per CU
+        if (ctx->park_bytes[slot] < park_need) {
+            RR_HIP(hipStreamSynchronize(ctx->stream));
+            dfree(ctx->d_park[slot]);
+            ctx->park_bytes[slot] = 0;
+            RR_HIP(hipMalloc(&ctx->d_park[slot], park_need));
+            ctx->park_bytes[slot] = park_need;
+        }
+        q.park = ctx->d_park[slot];
+        uint32_t rect[4];
+        mesh_screen_rect(m0->bounds, (ctx->dbg_ticket_blocks & 3) == 1 ? nullptr : h_cams, depth, width, height, rect);
+        // experiments (RR_DEBUG_TICKET): low bits 1 = whole frame in phase 1, 2 = no phase 1, 3 = phase 1 at every depth;
+        // +16: eight queues, a wave starts on its XCD's; +32: parked rays in registers
+        const int tk = ctx->dbg_ticket_blocks & 3;
+        if (tk == 2 || (depth > 4 && tk != 3 && tk != 1)) rect[2] = rect[0];
+        // eight queues, a wave starts on its XCD's: an XCD then works on every eighth slice, which its L2 rewards
+        // (monkey.obj Depth 64: 90 us per frame, 104 with 32 queues entered by wave number)
+        q.n_queues = (ctx->dbg_ticket_blocks & 16) ? LDS_QUEUES : 8u;
+        q.home_xcc = (ctx->dbg_ticket_blocks & 16) ? 0u : 1u;
+        q.dbg_regpark = (ctx->dbg_ticket_blocks & 32) ? 1u : 0u;
+        q.rx0 = rect[0]; q.ry0 = rect[1]; q.rx1 = rect[2]; q.ry1 = rect[3];
+        q.node_bytes = node_bytes;
+        q.stack_entries = need + 1;                     // the tree's depth bounds the stack; one entry to spare
+        RR_HIP(launch_render_lds(sc, a, q, ctx->n_cus, stats, ctx->stream, ctx->dbg_shape));
+    } else {
         // deep trees of small meshes: 16-bit stack entries keep eight waves per SIMD (LDS would otherwise allow 6/5/4)
-        bool stack16 = ctx->single_identity && need > 19 && need <= 39 && !getenv("RR_DEBUG_STACK") &&
+        bool stack16 = ctx->single_identity && need > 19 && need <= 39 && ctx->dbg_stack == 0 &&
                        ctx->meshes[(size_t)ctx->inst_host[0].blas].n_tris < 32768u;
         // one or two slices per launch: the tail of a few long waves sets the time, and those run faster without the
         // spills of the 6..8-wave builds (monkey Depth 1: 446 us with the 5-wave build, 475 with the 8-wave one)
-        if (depth <= 2 && ctx->single_identity && stack_sel < 31 && !getenv("RR_DEBUG_STACK")) { stack_sel = 31; stack16 = false; }
+        if (depth <= 2 && ctx->single_identity && stack_sel < 31 && ctx->dbg_stack == 0) { stack_sel = 31; stack16 = false; }
         if (depth <= 2) stack16 = false;
-        RR_HIP(launch_render_fused(sc, a, stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream, stack16));
+        RR_HIP(launch_render_fused(sc, a, stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream, stack16, ctx->dbg_kernel == 2));
     }
     if (timed) {
         RR_HIP(hipEventRecord(ctx->kev[(size_t)ctx->kev_used * 2 + 1], ctx->stream));
         ++ctx->kev_used;
     }
     if (d_diag) {       // experiments only: dump per-wave {start, cycles, max rays per lane, loop trips}
-        std::vector<unsigned long long> h((size_t)a.n_blocks * 16);
+        std::vector<unsigned long long> h(diag_waves * 4);
         RR_HIP(hipStreamSynchronize(ctx->stream));
         RR_HIP(hipMemcpy(h.data(), d_diag, h.size() * 8, hipMemcpyDeviceToHost));
         (void)hipFree(d_diag);
@@ -834,7 +961,7 @@ int rr_dispatch_rays(rr_context* ctx, uint32_t width, uint32_t height, const rr_
     rr_dispatch_params p;
     if (params) p = *params; else rr_default_dispatch_params(&p);
     if (int r = upload_cams(ctx, &ctx->cam, 1)) return r;
-    return dispatch_impl(ctx, width, height, 1, ctx->d_cams, p, nullptr, 0, false);
+    return dispatch_impl(ctx, width, height, 1, ctx->d_cams, &ctx->cam, p, nullptr, 0, false);
 }
 
 int rr_dispatch_rays_batch(rr_context* ctx, uint32_t width, uint32_t height, uint32_t depth,
@@ -845,7 +972,7 @@ int rr_dispatch_rays_batch(rr_context* ctx, uint32_t width, uint32_t height, uin
     rr_dispatch_params p;
     if (params) p = *params; else rr_default_dispatch_params(&p);
     if (int r = upload_cams(ctx, constants, depth)) return r;
-    return dispatch_impl(ctx, width, height, depth, ctx->d_cams, p, nullptr, 0, false);
+    return dispatch_impl(ctx, width, height, depth, ctx->d_cams, constants, p, nullptr, 0, false);
 }
 
 int rr_read_frame_slice(rr_context* ctx, uint32_t slice, uint8_t* rgba8, float* rgba32f)
@@ -934,7 +1061,7 @@ int orbit_impl(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispat
     // frames in flight: consecutive launches go to alternating lanes so that the long-running waves at the end of
     // one overlap the start of the next.  Not for timed dispatches (their durations must be exclusive).
     uint32_t lanes = ctx->frames_in_flight < n_batches ? ctx->frames_in_flight : n_batches;
-    if ((p.flags & RR_DISPATCH_TIME_KERNEL) || getenv("RR_DEBUG_DIAG")) lanes = 1;
+    if ((p.flags & RR_DISPATCH_TIME_KERNEL) || !ctx->dbg_diag.empty()) lanes = 1;
     if (host_out) {          // streaming to host: the copy of one region overlaps the rendering of the other
         if (ext_tiles || ctx->tile_world != 1 || (p.flags & RR_DISPATCH_FLOAT_OUTPUT))
             return fail(ctx, RR_ERR_UNSUPPORTED, "render_orbit_to_host: whole RGBA8 frames of an unsharded context only");
@@ -944,7 +1071,7 @@ int orbit_impl(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispat
         for (uint32_t k = 0; k < n_frames; k += batch) {
             const uint32_t d = n_frames - k < batch ? n_frames - k : batch;
             uint32_t* ext = ext_tiles ? ext_tiles + (size_t)k * ext_stride_elems : nullptr;
-            if (int rc = dispatch_impl(ctx, width, height, d, ctx->d_cams + k, p, ext, ext_stride_elems, k > 0 || keep_first)) return rc;
+            if (int rc = dispatch_impl(ctx, width, height, d, ctx->d_cams + k, cams.data() + k, p, ext, ext_stride_elems, k > 0 || keep_first)) return rc;
         }
         return RR_OK;
     }
@@ -971,7 +1098,7 @@ int orbit_impl(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispat
         const uint32_t d = n_frames - k < batch ? n_frames - k : batch;
         uint32_t* ext = ext_tiles ? ext_tiles + (size_t)k * ext_stride_elems : nullptr;
         ctx->stream = ctx->lane_stream[b % lanes];
-        rc = dispatch_impl(ctx, width, height, d, ctx->d_cams + k, p, ext, ext_stride_elems, true, b % lanes, batch);
+        rc = dispatch_impl(ctx, width, height, d, ctx->d_cams + k, cams.data() + k, p, ext, ext_stride_elems, true, b % lanes, batch);
         if (rc == RR_OK && host_out) {      // same lane: the region is not rendered into again before this copy is done
             const size_t fb = (size_t)width * height * 4;
             hipError_t e = hipMemcpyAsync(host_out + (size_t)k * fb, ctx->d_rgba8 + ctx->frame_base, (size_t)d * fb, hipMemcpyDeviceToHost, ctx->stream);
@@ -1190,6 +1317,25 @@ int rr_trace_rays(rr_context* ctx, const rr_ray* rays, uint32_t n, rr_hit* hits)
     RR_HIP(hipMemcpyAsync(&err, &ctx->d_cnt->error, 4, hipMemcpyDeviceToHost, ctx->stream));
     RR_HIP(hipStreamSynchronize(ctx->stream));
     if (err) return fail(ctx, RR_ERR_TRAVERSAL_OVERFLOW, "traversal stack overflow");
+    return RR_OK;
+}
+
+int rr_env_lookup(rr_context* ctx, const float* dirs, uint32_t n, float* rgb)
+{
+    if (int r = use_device(ctx)) return r;
+    if ((!dirs || !rgb) && n) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_env_lookup: null buffers");
+    if (n == 0) return RR_OK;
+    float *d_in = nullptr, *d_out = nullptr;
+    RR_HIP(hipMalloc(&d_in, (size_t)n * 12));
+    hipError_t e = hipMalloc(&d_out, (size_t)n * 12);
+    SceneDev sc;
+    fill_scene(ctx, sc);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, dirs, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = launch_env_lookup(sc, d_in, n, d_out, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(rgb, d_out, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(ctx, RR_ERR_DEVICE, "rr_env_lookup", e);
     return RR_OK;
 }
 

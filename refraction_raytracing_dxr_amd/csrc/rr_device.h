@@ -31,68 +31,65 @@ __device__ __forceinline__ f3 normalize3(f3 a)
 }
 
 // ---- spec'd atan2 / acos (Cephes single-precision minimax forms; HLSL's are implementation-defined)
-__device__ __forceinline__ float atan_pos(float x)
-{
-    float y0;
-    if (x > 2.414213562373095f) { y0 = 1.5707963267948966f; x = -(1.0f / x); }
-    else if (x > 0.4142135623730950f) { y0 = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
-    else { y0 = 0.0f; }
-    float z = x * x;
-    float p = ((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f;
-    float r = p * z * x + x;
-    return y0 + r;
-}
-
+// The oracle writes them with branches (oracle/rr_oracle.c: rro_atanf_pos, rro_atan2f, rro_asinf_core, rro_acosf).  Here
+// every lane evaluates ONE division chain, ONE square root and ONE polynomial, and the branches become selects of operands
+// and results: a wave whose lanes fall into different ranges would otherwise run every branch body in turn (the Miss
+// shader is a third of all vector instructions of a frame).  Each lane still performs exactly the operations of the
+// branch the oracle takes for its argument, so the bits are the same:
+//   atan range reduction   -(1/q) == (-1)/q,  (q-1)/(q+1) as is,  q == q/1   (IEEE division is exact in sign and by 1)
+//   acos                   0.5*(1+x) == 0.5*(1-|x|) for x < 0; the argument handed to the asin kernel is <= 0.5 in all
+//                          three ranges, so its own "> 0.5" branch is never taken
 __device__ __forceinline__ float rr_atan2f(float y, float x)
 {
-    if (x != x || y != y) return __builtin_nanf("");
-    if (y == 0.0f) {
-        if (x > 0.0f || (x == 0.0f && !__builtin_signbit(x))) return y;
-        return __builtin_signbit(y) ? -3.14159265358979323846f : 3.14159265358979323846f;
-    }
-    if (x == 0.0f) return y > 0.0f ? 1.5707963267948966f : -1.5707963267948966f;
-    float a = atan_pos(fabsf(y) / fabsf(x));
+    const float q = fabsf(y) / fabsf(x);
+    const bool big = q > 2.414213562373095f, mid = !big && q > 0.4142135623730950f;
+    const float num = big ? -1.0f : mid ? q - 1.0f : q;
+    const float den = big ? q : mid ? q + 1.0f : 1.0f;
+    const float y0 = big ? 1.5707963267948966f : mid ? 0.7853981633974483f : 0.0f;
+    const float xr = num / den;
+    const float z = xr * xr;
+    const float p = ((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f;
+    const float r = p * z * xr + xr;
+    float a = y0 + r;
     if (x < 0.0f) a = 3.14159265358979323846f - a;
-    return y < 0.0f ? -a : a;
-}
-
-__device__ __forceinline__ float asin_core(float a)
-{
-    float z, x;
-    bool flag = a > 0.5f;
-    if (flag) { z = 0.5f * (1.0f - a); x = sqrtf(z); }
-    else { x = a; z = x * x; }
-    float p = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z
-               + 1.6666752422e-1f);
-    float r = p * z * x + x;
-    if (flag) { r = r + r; r = 1.5707963267948966f - r; }
-    return r;
+    float res = y < 0.0f ? -a : a;
+    if (x == 0.0f) res = y > 0.0f ? 1.5707963267948966f : -1.5707963267948966f;
+    if (y == 0.0f) res = (x > 0.0f || (x == 0.0f && !__builtin_signbit(x))) ? y
+                                                                             : (__builtin_signbit(y) ? -3.14159265358979323846f : 3.14159265358979323846f);
+    if (x != x || y != y) res = __builtin_nanf("");
+    return res;
 }
 
 __device__ __forceinline__ float rr_acosf(float x)
 {
-    if (!(x >= -1.0f && x <= 1.0f)) return __builtin_nanf("");
-    if (x < -0.5f) return 3.14159265358979323846f - 2.0f * asin_core(sqrtf(0.5f * (1.0f + x)));
-    if (x > 0.5f) return 2.0f * asin_core(sqrtf(0.5f * (1.0f - x)));
-    float s = asin_core(fabsf(x));
-    if (x < 0.0f) s = -s;
-    return 1.5707963267948966f - s;
+    const float ax = fabsf(x);
+    const bool outer = ax > 0.5f;
+    const float a = outer ? sqrtf(0.5f * (1.0f - ax)) : ax;
+    const float z = a * a;
+    const float p = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z
+                     + 1.6666752422e-1f);
+    const float r = p * z * a + a;
+    const float two_r = 2.0f * r;
+    float res = outer ? (x < 0.0f ? 3.14159265358979323846f - two_r : two_r) : 1.5707963267948966f - (x < 0.0f ? -r : r);
+    if (!(x >= -1.0f && x <= 1.0f)) res = __builtin_nanf("");
+    return res;
 }
 
-// D3D ftou: truncate, NaN/negative -> 0, overflow -> 0xffffffff
+// D3D ftou: truncate, NaN/negative -> 0, overflow -> 0xffffffff: what v_cvt_u32_f32 does
 __device__ __forceinline__ uint32_t ftou(float f)
 {
-    if (!(f > 0.0f)) return 0u;
-    if (f >= 4294967296.0f) return 0xffffffffu;
-    return (uint32_t)f;
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
 }
 
-// typed UAV store to R8G8B8A8_UNORM (RefractionDemo.cpp:431)
+// typed UAV store to R8G8B8A8_UNORM (RefractionDemo.cpp:431): NaN -> 0, clamp, floor(x*255 + 0.5) (the conversion truncates,
+// which is the floor of a positive number)
 __device__ __forceinline__ uint32_t unorm8(float x)
 {
     if (!(x > 0.0f)) return 0u;
     if (x >= 1.0f) return 255u;
-    return (uint32_t)floorf(x * 255.0f + 0.5f);
+    return ftou(x * 255.0f + 0.5f);
 }
 
 // ---- TraceRay ------------------------------------------------------------------------------
@@ -163,6 +160,23 @@ __device__ __forceinline__ NodeQ load_node(const QNode* __restrict__ nodes, int 
     n.a = q[0]; n.b = q[1];
     return n;
 }
+// Where a BLAS's nodes are read from.  GlobalNodes: the QNode array in HBM, through the vector L1 (two global_load_dwordx4
+// per visit).  LdsNodes: a copy of the whole array in the workgroup's LDS (k_render_lds: two ds_read_b128 per visit) -- the
+// texture-addresser / L1 path is the busiest unit of the L1-fed kernel (TA busy 84 %, TD 97 %, 276 cycles per request:
+// profiles/r02_pmc_fused.txt) and an LDS read returns in a quarter of that time.
+struct GlobalNodes {
+    __device__ __forceinline__ NodeQ load(const QNode* __restrict__ nodes, int node) const { return load_node(nodes, node); }
+};
+struct LdsNodes {
+    const char* base;       // the copy (an address in LDS: every use is inlined into the kernel that owns the array)
+    __device__ __forceinline__ NodeQ load(const QNode* __restrict__, int node) const
+    {
+        const uint4* q = reinterpret_cast<const uint4*>(base + (uint32_t)node);
+        NodeQ n;
+        n.a = q[0]; n.b = q[1];
+        return n;
+    }
+};
 
 
 constexpr int TRAV_DONE = (int)0x80000000;     // neither an internal index (>= 0) nor a leaf (~i with i < 2^31-1)
@@ -312,9 +326,10 @@ __device__ __forceinline__ bool leaf_phase_due(int n_in)
 // "while-while" form: the lanes descend internal nodes (near child first, far child pushed) until enough of
 // them hold a leaf or have finished (leaf_phase_due); then the (expensive) triangle test is executed once for
 // all lanes that hold a leaf.
-template <bool STATS, class E>
+template <bool STATS, class E, class NS = GlobalNodes>
 __device__ __forceinline__ void trace_blas(const BlasDev& bl, f3 O, f3 D, float tmin, uint32_t cull, uint32_t inst,
-                                           HitRec& best, E* stk, TravCounters& cnt, const Diag dg = Diag{ nullptr })
+                                           HitRec& best, E* stk, TravCounters& cnt, const Diag dg = Diag{ nullptr },
+                                           const NS ns = NS{})
 {
     const BoxRay br = box_ray(O, D, bl.scale, bl.grid);
     const QNode* __restrict__ nodes = bl.nodes;
@@ -328,7 +343,7 @@ __device__ __forceinline__ void trace_blas(const BlasDev& bl, f3 O, f3 D, float 
         while (node >= 0) {
             if (leaf_phase_due(n_in)) break;
             diag_trip(dg);
-            const NodeQ q = load_node(nodes, node);
+            const NodeQ q = ns.load(nodes, node);
             if (STATS) cnt.nodes++;
             node = node_step(br, q, tmin, best.t, top, stk);
 #ifdef RR_EXP_EXTRA_VALU      // experiment: what do N more VALU instructions per visit cost?
@@ -367,15 +382,15 @@ __device__ __forceinline__ f3 xform_dir(const float* m, f3 p)
 // TLAS = false: the reference's scene, one BLAS.  TLAS = true: one loop over the flattened node pool;
 // reaching an instance leaf swaps the lane's ray for its object-space image (t is preserved: the
 // direction is not renormalised) and remembers the stack level, exhausting that level swaps it back.
-template <bool STATS, bool TLAS, class E = uint32_t>
+template <bool STATS, bool TLAS, class E = uint32_t, class NS = GlobalNodes>
 __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, float tmin, float tmax, uint32_t flags,
                                             HitRec& best, E* stk_e, TravCounters& cnt,
-                                            const Diag dg = Diag{ nullptr })
+                                            const Diag dg = Diag{ nullptr }, const NS ns = NS{})
 {
     best.t = tmax; best.hit = false; best.prim = 0; best.leaf = 0; best.inst = 0; best.U = 0.0f; best.V = 0.0f;
     best.ad = 1.0f;
     if (!TLAS) {      // the reference's scene: one identity instance, mask 1, flags 0 (RefractionDemo.cpp:324-334)
-        trace_blas<STATS, E>(sc.blas0, O, D, tmin, flags, 0u, best, stk_e, cnt, dg);
+        trace_blas<STATS, E, NS>(sc.blas0, O, D, tmin, flags, 0u, best, stk_e, cnt, dg, ns);
         return;
     }
     uint32_t* stk = reinterpret_cast<uint32_t*>(stk_e);      // the two-level loop always runs on 32-bit entries
@@ -462,12 +477,16 @@ __device__ __forceinline__ bool refract_ray(f3& R, f3 I, f3 N, float eta)
 }
 
 // ---- GenerateCameraRay: RayTracing.hlsl:27-40 ----------------------------------------------------
-__device__ __forceinline__ f3 camera_ray_dir(const float* M, uint32_t x, uint32_t y, uint32_t W, uint32_t H)
+// screen coordinate of a pixel centre (hlsl:29-33), the same operations for every pixel of a column / row: k_screen_tables
+// evaluates them once per column and row, the render kernels read the two tables
+__device__ __forceinline__ float screen_coord(uint32_t i, uint32_t n, bool flip)
 {
-    float px = (float)x + 0.5f, py = (float)y + 0.5f;
-    float sx = px / (float)W * 2.0f - 1.0f;
-    float sy = py / (float)H * 2.0f - 1.0f;
-    sy = -sy;
+    const float p = (float)i + 0.5f;
+    const float s = p / (float)n * 2.0f - 1.0f;
+    return flip ? -s : s;
+}
+__device__ __forceinline__ f3 camera_ray_dir(const float* M, float sx, float sy)
+{
     f3 R;
     R.x = (sx * M[0] + sy * M[1]) + M[3];
     R.y = (sx * M[4] + sy * M[5]) + M[7];

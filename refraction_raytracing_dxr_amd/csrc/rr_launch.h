@@ -12,9 +12,16 @@ static_assert(sizeof(rr_ray_dev) == 48 && sizeof(rr_hit_dev) == 24, "ABI layout"
 
 // ---- rr_render.hip
 hipError_t launch_render_fused(const SceneDev& sc, const DispatchDev& a, int stack, int pend, bool stats, hipStream_t s,
-                               bool stack16 = false);
+                               bool stack16 = false, bool async = false);
+// BLAS nodes in LDS, persistent workgroups (single identity instance whose node array fits: lds_kernel_shape() >= 0)
+// shapes (waves per workgroup x workgroups per CU): 0 = 12x2 (the product shape), 1 = 16x2, 2 = 16x1 (experiments:
+// RR_DEBUG_SHAPE = first shape to consider); -1: the node array does not fit
+int lds_kernel_shape(uint32_t node_bytes, uint32_t stack_entries, size_t* lds_bytes, int min_shape = 0);
+hipError_t launch_render_lds(const SceneDev& sc, const DispatchDev& a, LdsDispatch q, int n_cus, bool stats, hipStream_t s, int min_shape = 0);
 hipError_t launch_trace_rays(const SceneDev& sc, const rr_ray_dev* rays, uint32_t n, rr_hit_dev* hits, uint32_t* err,
                              int stack, hipStream_t s);
+hipError_t launch_screen_tables(float* out, uint32_t W, uint32_t H, hipStream_t s);
+hipError_t launch_env_lookup(const SceneDev& sc, const float* dirs, uint32_t n, float* rgb, hipStream_t s);
 hipError_t launch_assemble_tiles(const uint32_t* gathered, uint32_t* frame, uint32_t W, uint32_t H, uint32_t tiles_x,
                                  uint32_t n_tiles, uint32_t world, uint32_t max_tiles, hipStream_t s);
 // batched: strides in 32-bit words

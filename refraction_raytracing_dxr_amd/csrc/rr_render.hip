@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include "rr_device.h"
 #include "rr_launch.h"
 
@@ -53,6 +54,185 @@ __device__ __forceinline__ void block_to_tile(uint32_t b, uint32_t& tile_local, 
     strip = slot & 3u;
 }
 
+// per-lane tallies of one wave's work (reduced and added to the dispatch counters once, when the wave ends)
+struct LaneStats {
+    uint32_t rays = 0, hits = 0, miss = 0, term = 0, tir = 0, pixels = 0;
+    TravCounters cnt = { 0, 0 };
+};
+
+// One pixel: RayGen (RayTracing.hlsl:42-64), then the pixel's whole ray tree depth-first -- ClosestHit (hlsl:79-125)
+// spawns the refracted child (followed at once) and the reflected child (parked in registers), Miss (hlsl:127-137)
+// adds weight * texel.  Returns the pixel's colour, the sum of its leaves in the recursion's order.
+// Where a pixel's parked reflected rays wait.  RegPark: in registers (PEND slots of 8 words: they stay live through every
+// traversal and are most of what the 64-register builds spill).  MemPark: in a per-wave slab of device memory, field by
+// field, 64 lanes to a 256-byte row -- written once per spawned reflection and read once when it is resumed (0.3 times per
+// ray), so the traversal loops carry 8 * PEND registers less.
+template <int PEND>
+struct RegPark {
+    PendRay pend[PEND];
+    __device__ __forceinline__ void put(int k, const PendRay& p)
+    {
+#pragma unroll
+        for (int i = 0; i < PEND; ++i) if (i == k) pend[i] = p;
+    }
+    __device__ __forceinline__ PendRay get(int k) const
+    {
+        PendRay p = pend[0];
+#pragma unroll
+        for (int i = 1; i < PEND; ++i) if (i == k) p = pend[i];
+        return p;
+    }
+};
+struct MemPark {
+    uint32_t* base;         // this lane's column of the wave's slab: word f of slot k at base[(k * 8 + f) * 64]
+    __device__ __forceinline__ void put(int k, const PendRay& p)
+    {
+        uint32_t* q = base + (size_t)k * (8 * 64);
+        q[0 * 64] = __float_as_uint(p.ox); q[1 * 64] = __float_as_uint(p.oy); q[2 * 64] = __float_as_uint(p.oz);
+        q[3 * 64] = __float_as_uint(p.dx); q[4 * 64] = __float_as_uint(p.dy); q[5 * 64] = __float_as_uint(p.dz);
+        q[6 * 64] = __float_as_uint(p.w);  q[7 * 64] = p.meta;
+    }
+    __device__ __forceinline__ PendRay get(int k) const
+    {
+        const uint32_t* q = base + (size_t)k * (8 * 64);
+        PendRay p;
+        p.ox = __uint_as_float(q[0 * 64]); p.oy = __uint_as_float(q[1 * 64]); p.oz = __uint_as_float(q[2 * 64]);
+        p.dx = __uint_as_float(q[3 * 64]); p.dy = __uint_as_float(q[4 * 64]); p.dz = __uint_as_float(q[5 * 64]);
+        p.w = __uint_as_float(q[6 * 64]);  p.meta = q[7 * 64];
+        return p;
+    }
+};
+
+// may_hit (wave-uniform): false for a block outside the screen rectangle of the scene (DispatchDev::hx0..hy1) -- its
+// primary rays are Misses by construction and are not traced.
+template <bool STATS, bool TLAS, bool DIAG, class E, class NS, class PK>
+__device__ __forceinline__ f3 render_pixel(const SceneDev& sc, const DispatchDev& a, const CamDev& cb, uint32_t x, uint32_t y,
+                                           bool may_hit, E* stk, const NS ns, PK& park, LaneStats& st, uint32_t* diag_trips)
+{
+    f3 acc = mk3(0.0f, 0.0f, 0.0f);
+    int np = 0;
+    // RayGen: payload {color 0, mask 1, outside true, count 0}, CULL_BACK, [1e-4, 100]
+    f3 O = mk3(cb.cam[0], cb.cam[1], cb.cam[2]);
+    f3 D = camera_ray_dir(cb.M, a.sx[x], a.sy[y]);
+    float w = 1.0f;
+    uint32_t count = 0;
+    bool outside = true;
+    float tmin = a.tmin_p, tmax = a.tmax_p;
+    for (;;) {
+        HitRec h;
+        if (may_hit)
+            trace_scene<STATS, TLAS, E, NS>(sc, O, D, tmin, tmax, outside ? CULL_BACK : CULL_FRONT, h, stk, st.cnt,
+                                            Diag{ DIAG ? diag_trips : nullptr }, ns);
+        else h.hit = false;
+        may_hit = true;
+        ++st.rays;
+        if (DIAG) diag_trip(Diag{ diag_trips }, 2);
+        bool have_next = false;
+        if (!h.hit) {                                             // Miss
+            if (STATS) ++st.miss;
+            f3 e = env_lookup(sc, D);
+            acc.x = fmaf(w, e.x, acc.x); acc.y = fmaf(w, e.y, acc.y); acc.z = fmaf(w, e.z, acc.z);
+        } else {                                                  // ClosestHit
+            if (STATS) ++st.hits;
+            if ((int)count < a.max_refract) {                     // hlsl:82
+                f3 N = shading_normal<TLAS>(sc, h);
+                f3 X = mk3(fmaf(h.t, D.x, O.x), fmaf(h.t, D.y, O.y), fmaf(h.t, D.z, O.z));   // hlsl:88
+                f3 Nf = outside ? N : neg3(N);
+                const float R0 = (0.2f / 2.2f) * (0.2f / 2.2f);   // hlsl:92
+                float b = 1.0f - dot3(D, Nf);                     // hlsl:93, pow(b,5) = b*b*b*b*b
+                float b2 = b * b, b4 = b2 * b2;
+                float R = (R0 * (1.0f - R0)) * (b4 * b);
+                float eta = outside ? a.inv_ior : a.ior;          // hlsl:95
+                f3 d1;
+                bool refr = refract_ray(d1, D, Nf, eta);
+                if (STATS && !refr) ++st.tir;
+                bool refl = (int)count < a.max_reflect;           // hlsl:110
+                f3 d2 = mk3(0.0f, 0.0f, 0.0f);
+                if (refl) d2 = normalize3(reflect_ray(D, Nf));    // hlsl:113
+                const uint32_t c1 = count + 1u;
+                tmin = a.tmin_s; tmax = a.tmax_s;
+                O = X;
+                if (refr) {
+                    if (refl) {                                   // park the reflected child
+                        PendRay p;
+                        p.ox = X.x; p.oy = X.y; p.oz = X.z; p.dx = d2.x; p.dy = d2.y; p.dz = d2.z;
+                        p.w = w * R; p.meta = c1 | (outside ? 0x10000u : 0u);
+                        park.put(np, p);
+                        ++np;
+                    }
+                    D = d1; w = w * (1.0f - R); count = c1; outside = !outside;   // hlsl:103-107
+                    have_next = true;
+                } else if (refl) {
+                    D = d2; w = w * R; count = c1;                                // hlsl:118-122
+                    have_next = true;
+                }
+            } else if (STATS) {
+                ++st.term;                                        // payload.color stays 0
+            }
+        }
+        if (!have_next) {
+            if (np == 0) break;
+            --np;
+            const PendRay p = park.get(np);
+            O = mk3(p.ox, p.oy, p.oz); D = mk3(p.dx, p.dy, p.dz); w = p.w;
+            count = p.meta & 0xffffu; outside = (p.meta & 0x10000u) != 0u;
+            tmin = a.tmin_s; tmax = a.tmax_s;
+        }
+    }
+    return acc;
+}
+
+// RenderTarget[xy] = float4(color,1) -> R8G8B8A8_UNORM (hlsl:62); o: element index inside the slice
+__device__ __forceinline__ void store_pixel(const DispatchDev& a, uint32_t* out_rgba8, float4* out_f32, size_t o, f3 acc)
+{
+    const uint32_t packed = unorm8(acc.x) | (unorm8(acc.y) << 8) | (unorm8(acc.z) << 16) | 0xff000000u;
+    if (a.compact_out == 2u) {               // RGB8 tiles for the gather: alpha is always 255, not worth a link byte
+        uint8_t* p3 = reinterpret_cast<uint8_t*>(out_rgba8) + o * 3;
+        p3[0] = (uint8_t)packed; p3[1] = (uint8_t)(packed >> 8); p3[2] = (uint8_t)(packed >> 16);
+    } else {
+        out_rgba8[o] = packed;
+    }
+    if (out_f32) out_f32[o] = make_float4(acc.x, acc.y, acc.z, 1.0f);
+}
+
+// the wave's tallies -> dispatch counters: one sharded add per wave for the ray count, the rest only in STATS builds
+template <bool STATS>
+__device__ __forceinline__ void flush_stats(const DispatchDev& a, const LaneStats& st, uint32_t shard, uint32_t lane)
+{
+    uint32_t wr = wave_reduce_add(st.rays);
+    if (lane == 0 && wr) atomicAdd(&a.ray_shards[shard & (RAY_SHARDS - 1)], wr);
+    if (STATS) {
+        uint32_t v;
+        v = wave_reduce_add(st.hits);  if (lane == 0 && v) atomicAdd(&a.counters[C_HITS], (unsigned long long)v);
+        v = wave_reduce_add(st.miss);  if (lane == 0 && v) atomicAdd(&a.counters[C_MISSES], (unsigned long long)v);
+        v = wave_reduce_add(st.term);  if (lane == 0 && v) atomicAdd(&a.counters[C_TERMINAL], (unsigned long long)v);
+        v = wave_reduce_add(st.tir);   if (lane == 0 && v) atomicAdd(&a.counters[C_TIR], (unsigned long long)v);
+        v = wave_reduce_add(st.cnt.nodes); if (lane == 0 && v) atomicAdd(&a.counters[C_NODES], (unsigned long long)v);
+        v = wave_reduce_add(st.cnt.tris);  if (lane == 0 && v) atomicAdd(&a.counters[C_TRIS], (unsigned long long)v);
+        v = wave_reduce_add(st.pixels); if (lane == 0 && v) atomicAdd(&a.counters[C_PRIMARY], (unsigned long long)v);
+    }
+}
+
+// wave-block wb of the dispatch -> its slice (frame) and the 8x8 pixel block it covers.  Four consecutive wave-blocks are
+// the 32x8 strip one 256-thread workgroup of k_render_fused renders; strips of consecutive frames follow each other (the
+// depth slices are interleaved: mixing the slices keeps every CU on a blend of cheap background waves and expensive mesh
+// waves -- monkey.obj 1080p, Depth 16: 193 us/frame interleaved, 238 us slice after slice).
+struct BlockPos { uint32_t frame, tile_local, x0, y0, px0, py0; bool tile_ok; };
+__device__ __forceinline__ BlockPos wave_block_pos(const DispatchDev& a, uint32_t wb)
+{
+    BlockPos p;
+    const uint32_t blk = wb >> 2, wave = wb & 3u;
+    p.frame = blk % a.n_frames;
+    uint32_t strip;
+    block_to_tile(blk / a.n_frames, p.tile_local, strip);
+    p.tile_ok = p.tile_local < a.n_local_tiles;
+    const uint32_t tile = p.tile_local * a.tile_world + a.tile_rank;
+    const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    p.px0 = wave * 8u; p.py0 = strip * 8u;                         // inside the 32x32 tile
+    p.x0 = tx * TILE + p.px0; p.y0 = ty * TILE + p.py0;
+    return p;
+}
+
 template <int STACK, int PEND, bool STATS, bool TLAS, bool DIAG = false, class E = uint32_t>
 __global__ __launch_bounds__(256, TLAS ? RR_TLAS_WAVES_PER_SIMD(STACK) : sizeof(E) == 2 ? 8 : RR_FUSED_WAVES_PER_SIMD(STACK)) void k_render_fused(SceneDev sc, DispatchDev a)
 {
@@ -64,114 +244,27 @@ __global__ __launch_bounds__(256, TLAS ? RR_TLAS_WAVES_PER_SIMD(STACK) : sizeof(
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     E* stk = reinterpret_cast<E*>(lds) + wave * (STACK * 64) + lane;
 
-    // Depth slices are interleaved block by block (block b renders slice b % Depth): measured on MI355X,
-    // mixing the slices keeps every CU on a blend of cheap background waves and expensive mesh waves
-    // (monkey.obj 1080p, Depth 16: 193 us/frame interleaved, 238 us slice-after-slice, 747 us at Depth 1).
-    const uint32_t frame = blockIdx.x % a.n_frames;
-    uint32_t tile_local, strip;
-    block_to_tile(blockIdx.x / a.n_frames, tile_local, strip);
-    const bool tile_ok = tile_local < a.n_local_tiles;
-    const uint32_t tile = tile_local * a.tile_world + a.tile_rank;
-    const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const BlockPos bp = wave_block_pos(a, blockIdx.x * 4u + wave);
     const uint32_t lx = compact1by1(lane), ly = compact1by1(lane >> 1);
-    const uint32_t px = wave * 8u + lx, py = strip * 8u + ly;         // inside the 32x32 tile
-    const uint32_t x = tx * TILE + px, y = ty * TILE + py;
-    const bool valid = tile_ok && x < a.W && y < a.H;
-    const CamDev& cb = a.cams[frame];                                 // wave-uniform: scalar loads
-    uint32_t* const out_rgba8 = a.out_rgba8 + (size_t)frame * a.frame_stride;
-    float4* const out_f32 = a.out_f32 ? a.out_f32 + (size_t)frame * a.frame_stride : nullptr;
+    const uint32_t x = bp.x0 + lx, y = bp.y0 + ly;
+    const bool valid = bp.tile_ok && x < a.W && y < a.H;
+    const CamDev& cb = a.cams[bp.frame];                              // wave-uniform: scalar loads
+    uint32_t* const out_rgba8 = a.out_rgba8 + (size_t)bp.frame * a.frame_stride;
+    float4* const out_f32 = a.out_f32 ? a.out_f32 + (size_t)bp.frame * a.frame_stride : nullptr;
 
-    uint32_t n_rays = 0, n_hits = 0, n_miss = 0, n_term = 0, n_tir = 0;
-    TravCounters cnt; cnt.nodes = 0; cnt.tris = 0;
-    uint32_t err = 0;
-
-    f3 acc = mk3(0.0f, 0.0f, 0.0f);
+    LaneStats st;
     if (valid) {
-        PendRay pend[PEND];
-        int np = 0;
-        // RayGen: payload {color 0, mask 1, outside true, count 0}, CULL_BACK, [1e-4, 100]
-        f3 O = mk3(cb.cam[0], cb.cam[1], cb.cam[2]);
-        f3 D = camera_ray_dir(cb.M, x, y, a.W, a.H);
-        float w = 1.0f;
-        uint32_t count = 0;
-        bool outside = true;
-        float tmin = a.tmin_p, tmax = a.tmax_p;
-        for (;;) {
-            HitRec h;
-            trace_scene<STATS, TLAS, E>(sc, O, D, tmin, tmax, outside ? CULL_BACK : CULL_FRONT, h, stk, cnt,
-                                            Diag{ DIAG ? &diag_trips[threadIdx.x >> 6] : nullptr });
-            ++n_rays;
-            if (DIAG) diag_trip(Diag{ &diag_trips[threadIdx.x >> 6] }, 2);
-            bool have_next = false;
-            if (!h.hit) {                                             // Miss
-                if (STATS) ++n_miss;
-                f3 e = env_lookup(sc, D);
-                acc.x = fmaf(w, e.x, acc.x); acc.y = fmaf(w, e.y, acc.y); acc.z = fmaf(w, e.z, acc.z);
-            } else {                                                  // ClosestHit
-                if (STATS) ++n_hits;
-                if ((int)count < a.max_refract) {                     // hlsl:82
-                    f3 N = shading_normal<TLAS>(sc, h);
-                    f3 X = mk3(fmaf(h.t, D.x, O.x), fmaf(h.t, D.y, O.y), fmaf(h.t, D.z, O.z));   // hlsl:88
-                    f3 Nf = outside ? N : neg3(N);
-                    const float R0 = (0.2f / 2.2f) * (0.2f / 2.2f);   // hlsl:92
-                    float b = 1.0f - dot3(D, Nf);                     // hlsl:93, pow(b,5) = b*b*b*b*b
-                    float b2 = b * b, b4 = b2 * b2;
-                    float R = (R0 * (1.0f - R0)) * (b4 * b);
-                    float eta = outside ? a.inv_ior : a.ior;          // hlsl:95
-                    f3 d1;
-                    bool refr = refract_ray(d1, D, Nf, eta);
-                    if (STATS && !refr) ++n_tir;
-                    bool refl = (int)count < a.max_reflect;           // hlsl:110
-                    f3 d2 = mk3(0.0f, 0.0f, 0.0f);
-                    if (refl) d2 = normalize3(reflect_ray(D, Nf));    // hlsl:113
-                    const uint32_t c1 = count + 1u;
-                    tmin = a.tmin_s; tmax = a.tmax_s;
-                    O = X;
-                    if (refr) {
-                        if (refl) {                                   // park the reflected child
-                            PendRay p;
-                            p.ox = X.x; p.oy = X.y; p.oz = X.z; p.dx = d2.x; p.dy = d2.y; p.dz = d2.z;
-                            p.w = w * R; p.meta = c1 | (outside ? 0x10000u : 0u);
-#pragma unroll
-                            for (int k = 0; k < PEND; ++k) if (k == np) pend[k] = p;
-                            ++np;
-                        }
-                        D = d1; w = w * (1.0f - R); count = c1; outside = !outside;   // hlsl:103-107
-                        have_next = true;
-                    } else if (refl) {
-                        D = d2; w = w * R; count = c1;                                // hlsl:118-122
-                        have_next = true;
-                    }
-                } else if (STATS) {
-                    ++n_term;                                         // payload.color stays 0
-                }
-            }
-            if (!have_next) {
-                if (np == 0) break;
-                --np;
-                PendRay p = pend[0];
-#pragma unroll
-                for (int k = 1; k < PEND; ++k) if (k == np) p = pend[k];
-                O = mk3(p.ox, p.oy, p.oz); D = mk3(p.dx, p.dy, p.dz); w = p.w;
-                count = p.meta & 0xffffu; outside = (p.meta & 0x10000u) != 0u;
-                tmin = a.tmin_s; tmax = a.tmax_s;
-            }
-        }
-        // RenderTarget[xy] = float4(color,1) -> R8G8B8A8_UNORM (hlsl:62)
-        const uint32_t packed = unorm8(acc.x) | (unorm8(acc.y) << 8) | (unorm8(acc.z) << 16) | 0xff000000u;
+        st.pixels = 1;
+        RegPark<PEND> park;
+        const bool may_hit = DIAG || (bp.x0 + 8u > a.hx0 && bp.x0 < a.hx1 && bp.y0 + 8u > a.hy0 && bp.y0 < a.hy1);
+        const f3 acc = render_pixel<STATS, TLAS, DIAG, E, GlobalNodes>(sc, a, cb, x, y, may_hit, stk, GlobalNodes{}, park, st, &diag_trips[wave]);
         const size_t o = a.compact_out == 0u ? (size_t)y * a.W + x
-                                            : (size_t)tile_local * (TILE * TILE) + py * TILE + px;
-        if (a.compact_out == 2u) {               // RGB8 tiles for the gather: alpha is always 255, not worth a link byte
-            uint8_t* p3 = reinterpret_cast<uint8_t*>(out_rgba8) + o * 3;
-            p3[0] = (uint8_t)packed; p3[1] = (uint8_t)(packed >> 8); p3[2] = (uint8_t)(packed >> 16);
-        } else {
-            out_rgba8[o] = packed;
-        }
-        if (out_f32) out_f32[o] = make_float4(acc.x, acc.y, acc.z, 1.0f);
+                                            : (size_t)bp.tile_local * (TILE * TILE) + (bp.py0 + ly) * TILE + (bp.px0 + lx);
+        store_pixel(a, out_rgba8, out_f32, o, acc);
     }
 
     if (DIAG) {
-        uint32_t mx = n_rays;
+        uint32_t mx = st.rays;
         for (int off = 32; off > 0; off >>= 1) { uint32_t v = __shfl_xor(mx, off, 64); mx = v > mx ? v : mx; }
         if (lane == 0) {
             unsigned long long* d = a.diag + (size_t)(blockIdx.x * 4u + wave) * 4;
@@ -179,19 +272,129 @@ __global__ __launch_bounds__(256, TLAS ? RR_TLAS_WAVES_PER_SIMD(STACK) : sizeof(
             d[1] = __builtin_amdgcn_s_memtime() - diag_t0; d[2] = mx; d[3] = diag_trips[wave] + diag_trips[4 + wave];
         }
     }
-    // ray count: one sharded add per wave
-    uint32_t wr = wave_reduce_add(n_rays);
-    if (lane == 0 && wr) atomicAdd(&a.ray_shards[(blockIdx.x * 4u + wave) & (RAY_SHARDS - 1)], wr);
-    if (err) atomicOr(a.error_flag, 1u);
-    if (STATS) {
-        uint32_t v;
-        v = wave_reduce_add(n_hits);  if (lane == 0 && v) atomicAdd(&a.counters[C_HITS], (unsigned long long)v);
-        v = wave_reduce_add(n_miss);  if (lane == 0 && v) atomicAdd(&a.counters[C_MISSES], (unsigned long long)v);
-        v = wave_reduce_add(n_term);  if (lane == 0 && v) atomicAdd(&a.counters[C_TERMINAL], (unsigned long long)v);
-        v = wave_reduce_add(n_tir);   if (lane == 0 && v) atomicAdd(&a.counters[C_TIR], (unsigned long long)v);
-        v = wave_reduce_add(cnt.nodes); if (lane == 0 && v) atomicAdd(&a.counters[C_NODES], (unsigned long long)v);
-        v = wave_reduce_add(cnt.tris);  if (lane == 0 && v) atomicAdd(&a.counters[C_TRIS], (unsigned long long)v);
-        v = wave_reduce_add(valid ? 1u : 0u); if (lane == 0 && v) atomicAdd(&a.counters[C_PRIMARY], (unsigned long long)v);
+    flush_stats<STATS>(a, st, blockIdx.x * 4u + wave, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same renderer with the BLAS's nodes in LDS, for meshes whose whole node array fits beside the traversal stacks
+// (the reference's meshes up to shell.obj: 24-49 KB of QNodes).  Persistent workgroups of NW waves: each copies the node
+// array into its LDS once, then every wave pulls 8x8 pixel blocks (wave-blocks, numbered exactly as k_render_fused's) from
+// ticket counters until none are left.  Why: in the L1-fed kernel the texture addresser / L1 / data-return path is the
+// busiest unit after the VALU (TA 84 %, TD 97 % busy, 276 cycles per request; waves spend 53 % of their life in s_waitcnt:
+// profiles/r02_pmc_fused.txt); a divergent 32-byte node costs the CU's L1 56 cycles and its LDS 25 (tools/ubench_nodefetch.hip),
+// and a lone wave's trip shrinks from an L1 round trip to an LDS one, which is what the tail of a Depth-1 launch is made of.
+// Order of work (LdsDispatch): first the blocks inside the screen rectangle of the mesh, one per ticket, then the background
+// in runs of strips.  Tickets come from LDS_QUEUES counters per phase (rr_types.h); a wave whose own queue is empty drains
+// the others, so every block is rendered whatever the placement of workgroups is.
+// NW waves per workgroup, WGS workgroups per CU (NW * WGS / 4 waves per SIMD); stack entries are 16 bits (node index or
+// 0x8000 | leaf index: an LDS-resident array has fewer than 5 120 nodes).  After the last block the last wave to leave
+// zeroes the ticket words, so the next launch on the same slot needs no memset.
+template <int NW, int WGS, bool STATS, bool DIAG = false, int REGPARK = 0>
+__global__ __launch_bounds__(NW * 64, NW * WGS / 4) void k_render_lds(SceneDev sc, DispatchDev a, LdsDispatch q)
+{
+    typedef uint16_t E;
+    const unsigned long long diag_t0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long diag_wait = 0ull, diag_render = 0ull, diag_n = 0ull;       // cycles in ticket draws / in blocks, tickets | blocks << 32
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    {   // the BLAS's nodes -> LDS (q.node_bytes is a multiple of 32)
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(sc.blas0.nodes);
+        uint4* dst = reinterpret_cast<uint4*>(lds);
+        for (uint32_t i = threadIdx.x; i < q.node_bytes / 16u; i += NW * 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const LdsNodes ns{ reinterpret_cast<const char*>(lds) };
+    typename std::conditional<REGPARK == 0, MemPark, RegPark<REGPARK == 0 ? 1 : REGPARK> >::type park;
+    if constexpr (REGPARK == 0) park.base = q.park + (size_t)(blockIdx.x * NW + wave) * ((size_t)q.park_slots * 8 * 64) + lane;
+    E* stk = reinterpret_cast<E*>(reinterpret_cast<char*>(lds) + q.node_bytes) + wave * (q.stack_entries * 64u) + lane;
+    const uint32_t lx = compact1by1(lane), ly = compact1by1(lane >> 1);
+
+    LaneStats st;
+    auto in_rect = [&](const BlockPos& bp) { return bp.x0 >= q.rx0 && bp.x0 < q.rx1 && bp.y0 >= q.ry0 && bp.y0 < q.ry1; };
+    // The wave's work loop.  Everything that decides WHICH block comes next is wave-uniform (scalar); the renderer itself is
+    // instantiated once, at the bottom of the loop (its code is ~10 KB: several inlined copies thrash the instruction cache).
+    uint32_t home = (blockIdx.x * NW + wave) % q.n_queues;
+    if (q.home_xcc) { uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); home = (xcc & 7u) % q.n_queues; }
+    const uint32_t NQ = q.n_queues;
+    uint32_t phase = 0, qi = home;
+    bool stealing = false;
+    unsigned long long left = 0ull;            // queues still to drain after the wave's own
+    BlockPos strip;                            // the phase 2 ticket in hand: a 32x8 strip, rendered as four 8x8 blocks
+    uint32_t strip_j = 4u;
+    for (;;) {
+        BlockPos bp;
+        bool have = false;
+        while (!have) {
+            if (strip_j < 4u) {                                 // next block of the strip
+                bp = strip;
+                bp.px0 = strip_j * 8u; bp.x0 = strip.x0 + strip_j * 8u;
+                ++strip_j;
+                have = !in_rect(bp);
+                continue;
+            }
+            if (phase >= 2u) break;
+            const uint32_t total = phase == 0u ? q.p1_tickets : q.p2_tickets;
+            uint32_t* const cnt = q.tickets + phase * LDS_QUEUES * 16u;
+            if (total != 0u) {
+                const uint32_t n_tickets = total > qi ? (total - qi + NQ - 1u) / NQ : 0u;   // tickets qi, qi + LDS_QUEUES, ...
+                uint32_t t = 0;
+                const unsigned long long dw0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
+                if (lane == 0) t = atomicAdd(&cnt[qi * 16u], 1u);
+                t = __builtin_amdgcn_readfirstlane(t);
+                if (DIAG) { diag_wait += __builtin_amdgcn_s_memtime() - dw0; diag_n += 1ull; }
+                if (t < n_tickets) {
+                    const uint32_t u = qi + NQ * t;
+                    if (phase == 1u) {                          // strip u of the dispatch (wave-blocks 4u .. 4u+3)
+                        strip = wave_block_pos(a, u * 4u);
+                        strip_j = strip.tile_ok ? 0u : 4u;
+                    } else if (q.p1_direct) {                   // slice u % n_frames of rect block u / n_frames
+                        const uint32_t b = u / a.n_frames;
+                        bp.frame = u % a.n_frames; bp.tile_local = 0u; bp.px0 = 0u; bp.py0 = 0u; bp.tile_ok = true;
+                        bp.x0 = q.rx0 + (b % q.rect_bw) * 8u; bp.y0 = q.ry0 + (b / q.rect_bw) * 8u;
+                        have = true;
+                    } else {                                    // wave-block u, if it lies inside the rectangle
+                        bp = wave_block_pos(a, u);
+                        have = bp.tile_ok && in_rect(bp);
+                    }
+                    continue;
+                }
+                // this queue is empty.  The others: one look at all counters (read past the L1; they only ever grow, so a
+                // queue seen empty stays empty)
+                if (!stealing) {
+                    const uint32_t seen = lane < NQ ? __hip_atomic_load(&cnt[lane * 16u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+                    const uint32_t mine = total > lane ? (total - lane + NQ - 1u) / NQ : 0u;
+                    left = __ballot(lane < NQ && lane != home && seen < mine);
+                    stealing = true;
+                }
+                if (left) { qi = (uint32_t)__ffsll((long long)left) - 1u; left &= left - 1ull; continue; }
+            }
+            ++phase; qi = home; stealing = false;
+        }
+        if (!have) break;
+        const unsigned long long dr0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
+        const uint32_t x = bp.x0 + lx, y = bp.y0 + ly;
+        if (x < a.W && y < a.H) {
+            const CamDev& cb = a.cams[bp.frame];
+            st.pixels += 1;
+            const bool may_hit = bp.x0 + 8u > a.hx0 && bp.x0 < a.hx1 && bp.y0 + 8u > a.hy0 && bp.y0 < a.hy1;
+            const f3 acc = render_pixel<STATS, false, false, E, LdsNodes>(sc, a, cb, x, y, may_hit, stk, ns, park, st, nullptr);
+            const size_t o = a.compact_out == 0u ? (size_t)y * a.W + x
+                                                : (size_t)bp.tile_local * (TILE * TILE) + (bp.py0 + ly) * TILE + (bp.px0 + lx);
+            store_pixel(a, a.out_rgba8 + (size_t)bp.frame * a.frame_stride,
+                        a.out_f32 ? a.out_f32 + (size_t)bp.frame * a.frame_stride : nullptr, o, acc);
+        }
+        if (DIAG) { diag_render += __builtin_amdgcn_s_memtime() - dr0; diag_n += 1ull << 32; }
+    }
+    if (DIAG && lane == 0) {
+        unsigned long long* d = a.diag + (size_t)(blockIdx.x * NW + wave) * 4;
+        d[0] = diag_wait; d[1] = diag_render; d[2] = diag_n; d[3] = __builtin_amdgcn_s_memtime() - diag_t0;
+    }
+    flush_stats<STATS>(a, st, blockIdx.x * NW + wave, lane);
+    if (lane == 0) {        // every ticket this wave drew came back before this add: the last arrival sees all queues drained
+        const uint32_t arrived = atomicAdd(&q.tickets[2u * LDS_QUEUES * 16u], 1u);
+        if (arrived + 1u == gridDim.x * NW) {
+            for (uint32_t k = 0; k <= 2u * LDS_QUEUES; ++k) atomicExch(&q.tickets[k * 16u], 0u);
+        }
     }
 }
 
@@ -242,7 +445,7 @@ __global__ __launch_bounds__(256) void k_render_async(SceneDev sc, DispatchDev a
     PendRay pend[PEND];
     int np = 0;
     f3 O = mk3(cb.cam[0], cb.cam[1], cb.cam[2]);                    // RayGen, RayTracing.hlsl:42-60
-    f3 D = valid ? camera_ray_dir(cb.M, x, y, a.W, a.H) : mk3(1.0f, 0.0f, 0.0f);
+    f3 D = valid ? camera_ray_dir(cb.M, a.sx[x], a.sy[y]) : mk3(1.0f, 0.0f, 0.0f);
     float w = 1.0f;
     uint32_t count = 0;
     bool outside = true;
@@ -384,6 +587,23 @@ __global__ __launch_bounds__(256) void k_render_async(SceneDev sc, DispatchDev a
         v = wave_reduce_add(n_tris);  if (lane == 0 && v) atomicAdd(&a.counters[C_TRIS], (unsigned long long)v);
         v = wave_reduce_add(valid ? 1u : 0u); if (lane == 0 && v) atomicAdd(&a.counters[C_PRIMARY], (unsigned long long)v);
     }
+}
+
+// GenerateCameraRay's per-column and per-row screen coordinates (RayTracing.hlsl:29-33): out[0..W) = sx, out[W..W+H) = sy
+__global__ __launch_bounds__(256) void k_screen_tables(float* out, uint32_t W, uint32_t H)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < W) out[i] = screen_coord(i, W, false);
+    else if (i < W + H) out[i] = screen_coord(i - W, H, true);
+}
+
+// Miss in isolation, for the parity tests (rr_env_lookup): dirs / rgb are n x 3 floats
+__global__ __launch_bounds__(256) void k_env_lookup(SceneDev sc, const float* dirs, uint32_t n, float* rgb)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const f3 e = env_lookup(sc, mk3(dirs[i * 3], dirs[i * 3 + 1], dirs[i * 3 + 2]));
+    rgb[i * 3] = e.x; rgb[i * 3 + 1] = e.y; rgb[i * 3 + 2] = e.z;
 }
 
 // TraceRay in isolation, for the parity tests (rr_trace_rays)
@@ -568,7 +788,7 @@ __global__ __launch_bounds__(256, RR_FUSED_WAVES_PER_SIMD(STACK)) void k_wf_prim
     if (valid) {
         WfRay r;
         r.O = mk3(cb.cam[0], cb.cam[1], cb.cam[2]);
-        r.D = camera_ray_dir(cb.M, x, y, a.W, a.H);
+        r.D = camera_ray_dir(cb.M, a.sx[x], a.sy[y]);
         r.w = 1.0f; r.count = 0u; r.slot = 0u; r.outside = true;
         r.pix = (uint32_t)((size_t)frame * a.frame_stride + (size_t)y * a.W + x);
         HitRec h;
@@ -679,25 +899,74 @@ static hipError_t launch_async_sp(const SceneDev& sc, const DispatchDev& a, bool
     return hipGetLastError();
 }
 
-// default: the lock-step kernel (best throughput once several slices are in flight); RR_DEBUG_KERNEL=async
-// selects the lane-asynchronous one (shorter worst wave on irregular meshes, costlier trips)
-
-static int kernel_choice()      // 1 lock-step (default), 2 lane-asynchronous
+template <int NW, int WGS>
+static hipError_t launch_lds_nw(const SceneDev& sc, const DispatchDev& a, const LdsDispatch& q, size_t lds, int n_cus, bool stats, hipStream_t s)
 {
-    static const int v = [] {
-        const char* e = getenv("RR_DEBUG_KERNEL");
-        return (e && !strcmp(e, "async")) ? 2 : 1;
+    static const hipError_t attr = [] {       // more than 64 KB of dynamic LDS has to be asked for, once per instantiation
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_lds<NW, WGS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_lds<NW, WGS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return e;
     }();
-    return v;
+    if (attr != hipSuccess) return attr;
+    const dim3 grid((uint32_t)n_cus * WGS), block(NW * 64);
+    if (stats) hipLaunchKernelGGL((k_render_lds<NW, WGS, true>), grid, block, lds, s, sc, a, q);
+    else       hipLaunchKernelGGL((k_render_lds<NW, WGS, false>), grid, block, lds, s, sc, a, q);
+    return hipGetLastError();
 }
 
-static bool use_sync_kernel() { return kernel_choice() != 2; }
+// Workgroup shapes of k_render_lds; a shape fits when the node array plus its stacks fit the CU's LDS WGS times (limit per
+// workgroup: 160 KiB / WGS, less a little for the allocation granule).  12 waves x 2 workgroups (6 waves per SIMD, 80
+// registers) is the one that pays: 16 x 2 (8 waves, 64 registers) spills 28 words per lane and 8 192 waves' scratch no
+// longer fits the L2 (monkey.obj Depth 64: 90 us per frame against 83), 16 x 1 leaves 4 waves per SIMD (109 us).
+int lds_kernel_shape(uint32_t node_bytes, uint32_t stack_entries, size_t* lds_bytes, int min_shape)
+{
+    static const struct { int nw, wgs; } shapes[] = { { 12, 2 }, { 16, 2 }, { 16, 1 } };
+    for (int i = min_shape < 0 ? 0 : min_shape; i < 3; ++i) {
+        const size_t need = (size_t)node_bytes + (size_t)shapes[i].nw * stack_entries * 64 * sizeof(uint16_t);
+        if (need <= (size_t)(160 * 1024) / shapes[i].wgs - 512) { if (lds_bytes) *lds_bytes = need; return i; }
+        if (min_shape <= 0) break;       // product path: the first shape or none
+    }
+    return -1;
+}
 
+hipError_t launch_render_lds(const SceneDev& sc, const DispatchDev& a, LdsDispatch q, int n_cus, bool stats, hipStream_t s, int min_shape)
+{
+    if (a.n_blocks == 0) return hipSuccess;
+    size_t lds = 0;
+    const int shape = lds_kernel_shape(q.node_bytes, q.stack_entries, &lds, min_shape);
+    if (shape < 0) return hipErrorInvalidValue;
+    q.wave_blocks = a.n_blocks * 4u;
+    q.p2_strips = 1u;
+    q.p2_tickets = a.n_blocks;                  // one 32x8 strip (four wave-blocks) per ticket
+    const bool rect = q.rx1 > q.rx0 && q.ry1 > q.ry0;
+    q.rect_bw = rect ? (q.rx1 - q.rx0) / 8u : 0u;
+    q.p1_direct = (a.compact_out == 0u && a.tile_world == 1u) ? 1u : 0u;
+    q.p1_tickets = !rect ? 0u : q.p1_direct ? q.rect_bw * ((q.ry1 - q.ry0) / 8u) * a.n_frames : q.wave_blocks;
+    if (a.diag) {       // diagnostic build (RR_DEBUG_DIAG): per-wave cycles in ticket draws and in blocks; 12x2 shape
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_lds<12, 2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (attr != hipSuccess) return attr;
+        const size_t l12 = (size_t)q.node_bytes + (size_t)12 * q.stack_entries * 64 * sizeof(uint16_t);
+        hipLaunchKernelGGL((k_render_lds<12, 2, false, true>), dim3((uint32_t)n_cus * 2), dim3(12 * 64), l12, s, sc, a, q);
+        return hipGetLastError();
+    }
+    if (q.dbg_regpark && shape == 1 && q.park_slots <= 2u && !stats) {      // experiment: parked rays in registers
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_lds<16, 2, false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (attr != hipSuccess) return attr;
+        hipLaunchKernelGGL((k_render_lds<16, 2, false, false, 2>), dim3((uint32_t)n_cus * 2), dim3(16 * 64), lds, s, sc, a, q);
+        return hipGetLastError();
+    }
+    if (shape == 0) return launch_lds_nw<12, 2>(sc, a, q, lds, n_cus, stats, s);
+    if (shape == 1) return launch_lds_nw<16, 2>(sc, a, q, lds, n_cus, stats, s);
+    return launch_lds_nw<16, 1>(sc, a, q, lds, n_cus, stats, s);
+}
+
+// default: the lock-step kernel (best throughput once several slices are in flight); async: the lane-asynchronous one
+// (RR_DEBUG_KERNEL=async, read by rr_create: shorter worst wave on irregular meshes, costlier trips)
 template <int STACK, int PEND>
-static hipError_t launch_fused_sp(const SceneDev& sc, const DispatchDev& a, bool stats, hipStream_t s)
+static hipError_t launch_fused_sp(const SceneDev& sc, const DispatchDev& a, bool stats, hipStream_t s, bool async)
 {
     if (!sc.single_identity) return launch_fused_spt<STACK, PEND, true>(sc, a, stats, s);
-    if (use_sync_kernel()) return launch_fused_spt<STACK, PEND, false>(sc, a, stats, s);
+    if (!async) return launch_fused_spt<STACK, PEND, false>(sc, a, stats, s);
     return launch_async_sp<STACK, PEND>(sc, a, stats, s);
 }
 
@@ -712,22 +981,22 @@ static hipError_t launch_fused_s16(const SceneDev& sc, const DispatchDev& a, boo
     return hipGetLastError();
 }
 
-hipError_t launch_render_fused(const SceneDev& sc, const DispatchDev& a, int stack, int pend, bool stats, hipStream_t s, bool stack16)
+hipError_t launch_render_fused(const SceneDev& sc, const DispatchDev& a, int stack, int pend, bool stats, hipStream_t s, bool stack16, bool async)
 {
     if (a.n_blocks == 0) return hipSuccess;
-    if (stack16 && !a.diag && sc.single_identity && use_sync_kernel() && stack <= 39)
+    if (stack16 && !a.diag && sc.single_identity && !async && stack <= 39)
         return pend <= 2 ? launch_fused_s16<2>(sc, a, stats, s) : launch_fused_s16<8>(sc, a, stats, s);
     if (a.diag) {       // diagnostic builds of the reference-scene kernels (never used by the product path)
-        if (use_sync_kernel()) hipLaunchKernelGGL((k_render_fused<31, 2, false, false, true>), dim3(a.n_blocks), dim3(256), 4 * 31 * 64 * 4, s, sc, a);
+        if (!async) hipLaunchKernelGGL((k_render_fused<31, 2, false, false, true>), dim3(a.n_blocks), dim3(256), 4 * 31 * 64 * 4, s, sc, a);
         else hipLaunchKernelGGL((k_render_async<31, 2, false, true>), dim3(a.n_blocks), dim3(256), 4 * 31 * 64 * 4, s, sc, a);
         return hipGetLastError();
     }
-    if (stack <= 19 && pend <= 2) return launch_fused_sp<19, 2>(sc, a, stats, s);
-    if (stack <= 22 && pend <= 2) return launch_fused_sp<22, 2>(sc, a, stats, s);
-    if (stack <= 26 && pend <= 2) return launch_fused_sp<26, 2>(sc, a, stats, s);
-    if (stack <= 31) return pend <= 2 ? launch_fused_sp<31, 2>(sc, a, stats, s) : launch_fused_sp<31, 8>(sc, a, stats, s);
-    if (stack <= 39) return pend <= 2 ? launch_fused_sp<39, 2>(sc, a, stats, s) : launch_fused_sp<39, 8>(sc, a, stats, s);
-    return pend <= 2 ? launch_fused_sp<64, 2>(sc, a, stats, s) : launch_fused_sp<64, 8>(sc, a, stats, s);
+    if (stack <= 19 && pend <= 2) return launch_fused_sp<19, 2>(sc, a, stats, s, async);
+    if (stack <= 22 && pend <= 2) return launch_fused_sp<22, 2>(sc, a, stats, s, async);
+    if (stack <= 26 && pend <= 2) return launch_fused_sp<26, 2>(sc, a, stats, s, async);
+    if (stack <= 31) return pend <= 2 ? launch_fused_sp<31, 2>(sc, a, stats, s, async) : launch_fused_sp<31, 8>(sc, a, stats, s, async);
+    if (stack <= 39) return pend <= 2 ? launch_fused_sp<39, 2>(sc, a, stats, s, async) : launch_fused_sp<39, 8>(sc, a, stats, s, async);
+    return pend <= 2 ? launch_fused_sp<64, 2>(sc, a, stats, s, async) : launch_fused_sp<64, 8>(sc, a, stats, s, async);
 }
 
 template <int STACK, bool TLAS>
@@ -742,6 +1011,19 @@ hipError_t launch_trace_rays(const SceneDev& sc, const rr_ray_dev* rays, uint32_
     if (n == 0) return hipSuccess;
     if (stack <= 31) { if (sc.single_identity) launch_trace_st<31, false>(sc, rays, n, hits, err, s); else launch_trace_st<31, true>(sc, rays, n, hits, err, s); }
     else             { if (sc.single_identity) launch_trace_st<64, false>(sc, rays, n, hits, err, s); else launch_trace_st<64, true>(sc, rays, n, hits, err, s); }
+    return hipGetLastError();
+}
+
+hipError_t launch_screen_tables(float* out, uint32_t W, uint32_t H, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_screen_tables, dim3((W + H + 255u) / 256u), dim3(256), 0, s, out, W, H);
+    return hipGetLastError();
+}
+
+hipError_t launch_env_lookup(const SceneDev& sc, const float* dirs, uint32_t n, float* rgb, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_env_lookup, dim3((n + 255u) / 256u), dim3(256), 0, s, sc, dirs, n, rgb);
     return hipGetLastError();
 }
 

@@ -115,6 +115,9 @@ struct DispatchDev {
     int32_t max_refract, max_reflect;
     float ior, inv_ior;
     float tmin_p, tmax_p, tmin_s, tmax_s;
+    const float* sx;                // GenerateCameraRay's screen coordinates, one per column / row (k_screen_tables):
+    const float* sy;                //   sx[x] = (x + 0.5) / W * 2 - 1,  sy[y] = -((y + 0.5) / H * 2 - 1)
+    uint32_t hx0, hy0, hx1, hy1;    // pixels outside this rectangle cannot see the scene: their primary ray is a Miss without a trace
     uint32_t* out_rgba8;            // world==1: W*H raster; else compact tiles
     float4*   out_f32;              // optional, same addressing
     unsigned long long* counters;   // rr::Counter slots
@@ -122,6 +125,38 @@ struct DispatchDev {
     uint32_t* error_flag;
     unsigned long long* diag;       // diagnostic builds only: 4 x u64 per wave {start, cycles, rays(max lane), loop trips}
 };
+
+// k_render_lds (persistent workgroups, BLAS nodes in LDS): the work queues of one launch.
+// Work is handed out in two phases.  Phase 1 (launches of few slices, whose length is set by their most expensive blocks):
+// the 8x8 pixel blocks inside the screen rectangle that bounds the mesh in every slice of the launch (the projection of the
+// BLAS bounds, computed by the host from the slices' constants), one block per ticket -- these hold every secondary ray,
+// i.e. every expensive block, and start first so that the launch does not end on them.  Phase 2: every 32x8 strip of the
+// dispatch in image order, slices interleaved, one per ticket, minus the blocks phase 1 rendered.  Launches of many slices
+// have no phase 1: image order mixes cheap background blocks (arithmetic only) with mesh blocks (LDS traffic) on every CU,
+// which is worth more than an early start of the expensive ones (monkey.obj, Depth 64: 3.9 % of wave time idle at the end).
+struct LdsDispatch {
+    uint32_t* tickets;          // LDS_TICKET_WORDS words, one counter per 64-byte line: phase 1 queues, phase 2 queues, finished waves
+    uint32_t p1_tickets;        // phase 1: rect blocks * slices (direct) or all wave-blocks (scan), see p1_direct
+    uint32_t p1_direct;         // 1: ticket t is slice t % n_frames of rect block t / n_frames (unsharded raster frames);
+                                // 0: ticket t is wave-block t of the dispatch, rendered only if it lies inside the rectangle
+    uint32_t rect_bw;           // rectangle width in 8x8 blocks
+    uint32_t rx0, ry0, rx1, ry1;// the rectangle in pixels, multiples of 8 (rx1 <= rx0: empty)
+    uint32_t p2_tickets;        // phase 2: strips of the dispatch
+    uint32_t p2_strips;         // 1
+    uint32_t wave_blocks;       // 4 per 32x8 strip block of the dispatch
+    uint32_t n_queues;          // ticket queues per phase in use (<= LDS_QUEUES)
+    uint32_t home_xcc;          // 1: a wave's first queue is its XCD's number, 0: its own number, modulo n_queues
+    uint32_t dbg_regpark;       // experiments: parked rays in registers
+    uint32_t* park;             // parked reflected rays: [wave of the grid][park_slots][8 words][64 lanes]
+    uint32_t park_slots;        // >= max_reflect
+    uint32_t node_bytes;        // size of the node array copied to LDS (multiple of 32)
+    uint32_t stack_entries;     // per-lane traversal stack entries (> tree depth)
+};
+// Ticket counters: one word saturates near 88 dequeues per microsecond (MI355X_MICROARCH.md "dequeue") and 8 192 waves pull
+// from them, so each phase has LDS_QUEUES of them (ticket u belongs to queue u % LDS_QUEUES); a wave starts on the queue
+// of its own number and, once that is empty, reads all counters with one load and drains whichever are not.
+constexpr uint32_t LDS_QUEUES = 32;
+constexpr uint32_t LDS_TICKET_WORDS = (2 * LDS_QUEUES + 1) * 16;
 
 enum Counter : int {
     C_RAYS = 0, C_PRIMARY, C_SECONDARY, C_HITS, C_MISSES, C_TERMINAL, C_TIR, C_NODES, C_TRIS, C_COUNT

@@ -307,6 +307,13 @@ class Renderer:
         self._ck(self._L.rr_trace_rays(self._h, rays.ctypes.data, len(rays), hits.ctypes.data), "rr_trace_rays")
         return hits
 
+    def env_lookup(self, dirs):
+        """Miss (RayTracing.hlsl:127-137) on an [n,3] array of directions -> [n,3] texels."""
+        dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        out = np.zeros_like(dirs)
+        self._ck(self._L.rr_env_lookup(self._h, dirs.ctypes.data, len(dirs), out.ctypes.data), "rr_env_lookup")
+        return out
+
     def download_blas(self, mesh_id):
         nn, nt = C.c_uint32(), C.c_uint32()
         self._ck(self._L.rr_download_blas(self._h, mesh_id, None, C.byref(nn), None, C.byref(nt)), "rr_download_blas")

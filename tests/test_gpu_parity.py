@@ -203,6 +203,48 @@ def test_trace_rays_awkward_geometry_vs_brute_force(gpu, kind, n, fast_build):
     assert n_hit >= (20 if n >= 100 else 0)       # (tiny soups offer little to hit; "mixed, 1" is a single degenerate triangle)
 
 
+def test_miss_shader_bit_exact_incl_out_of_range_texels(gpu):
+    """Miss (RayTracing.hlsl:127-137) in isolation, GPU against oracle, bit for bit: the texture edges the shader can
+    reach because it divides by the literal 3.14159 (atan2 = pi -> theta >= W; r.y = -1 -> phi >= H: zero texel,
+    SURVEY A.2), the axes, signed zeros, every range of the atan / acos range reduction, and 20 000 random directions."""
+    m = load("cube.obj")
+    env = (np.arange(8 * 4 * 3, dtype=np.float32).reshape(4, 8, 3) + 1.0)
+    gpu_scene(gpu, [m], env)
+    s = oracle_scene([m], env)
+    rng = np.random.default_rng(11)
+    d = rng.standard_normal((20000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    edge = [(0, 0, -1), (0, -1, 0), (0, 1, 0), (1, 0, 0), (-1, 0, 0), (0, 0, 1), (-0.0, 0, -1), (0.0, -0.0, -1), (-0.0, -1, -0.0),
+            (1e-8, 0, -1), (-1e-8, 0, -1), (0, -0.99999994, 0.00034526698), (0, 0.5, 0.8660254), (0, -0.5, 0.8660254),
+            (0, 0.50000006, 0.8660254), (0, -0.50000006, -0.8660254)]
+    for q in (0.41421354, 0.4142136, 2.4142134, 2.4142137, 1.0, 1e-30, 1e30):           # atan range-reduction boundaries
+        for sx in (1.0, -1.0):
+            for sz in (1.0, -1.0):
+                v = np.array([sx * q, 0.1, sz], np.float64); v /= np.linalg.norm(v)
+                edge.append(tuple(v))
+    dirs = np.concatenate([np.array(edge, np.float32), d])
+    got = gpu.env_lookup(dirs)
+    ref = np.stack([s.env_lookup(tuple(float(c) for c in v)) for v in dirs])
+    assert np.array_equal(got.view(np.uint32), ref.astype(np.float32).view(np.uint32))
+    assert np.array_equal(got[0], (0, 0, 0)) and np.array_equal(got[1], (0, 0, 0))      # the two out-of-range texels
+    assert np.array_equal(got[2], env[0, 4]) and np.array_equal(got[3], env[2, 6])
+
+
+def test_out_of_range_texel_through_dispatch_rays(gpu):
+    """The same two edges through rr_dispatch_rays: a 1x1 frame whose only ray leaves along -z / -y and misses."""
+    m = load("cube.obj")
+    env = np.full((4, 8, 3), 0.75, np.float32)
+    gpu_scene(gpu, [m], env)
+    for direction, expect in (((0, 0, -1), 0.0), ((0, -1, 0), 0.0), ((0, 1, 0), 0.75)):
+        M = np.zeros((4, 4), np.float32)
+        M[0, 3], M[1, 3], M[2, 3] = direction                    # R = M * (sx, sy, 0, 1): the constant column is the direction
+        gpu.set_camera(rr.scene_constants(M.reshape(16), (50.0, 50.0, 50.0, 1.0)))
+        gpu.dispatch_rays(1, 1, rr.default_params(flags=rr.DISPATCH_FLOAT_OUTPUT))
+        rgba, f32 = gpu.read_frame(want_float=True)
+        assert np.array_equal(f32[0, 0, :3], np.full(3, expect, np.float32)), (direction, f32)
+        assert rgba[0, 0, 0] == (0 if expect == 0.0 else 191)
+
+
 def test_experimental_wavefront_kernels_render_the_same_frames(tmp_path):
     """RR_DEBUG_KERNEL=wavefront (queue-per-bounce kernels kept for comparison): bit-identical frames to
     the fused kernel, whatever order the queues fill in.  Own processes: the switch is read once per process."""
@@ -229,6 +271,45 @@ def test_experimental_wavefront_kernels_render_the_same_frames(tmp_path):
         res[k] = (np.load(tmp_path / (k + ".npy")), int(p.stdout.split()[-1]))
     assert np.array_equal(res["fused"][0], res["wavefront"][0])
     assert res["fused"][1] == res["wavefront"][1]                      # and the same number of TraceRay calls
+
+
+def test_lds_kernel_renders_the_same_frames(tmp_path):
+    """k_render_lds (persistent workgroups, BLAS nodes in LDS, tickets, reflected rays parked in memory) against
+    k_render_fused and against the oracle: every frame byte for byte, float colours bit for bit, the same counters --
+    at Depth 1 (mesh rectangle first), Depth 5 / 40 (image order), with float output, with stats, sharded tiles (the
+    scan form of the ticket order) and for each workgroup shape.  Own processes: the switches are read at rr_create."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import refraction_raytracing_dxr_amd as rr\n"
+        "from refraction_raytracing_dxr_amd.synth import asset, procedural_env\n"
+        "r = rr.Renderer(0); out = []; cnt = []\n"
+        "for name, kw in (('monkey.obj', dict(max_refract=8)), ('sphere.obj', dict(max_refract=4, max_reflect=1)), ('shell.obj', dict(max_reflect=4)), ('cube.obj', dict())):\n"
+        "    m = rr.Mesh(); m.load(asset(name))\n"
+        "    r.load_scene(m.verts, m.indices, procedural_env(256, 128, seed=9))\n"
+        "    for depth, frames in ((1, 2), (5, 5), (40, 40)):\n"
+        "        r.render_orbit(323, 181, frames, angle=0.3, params=rr.default_params(flags=rr.DISPATCH_COLLECT_STATS | rr.DISPATCH_FLOAT_OUTPUT, **kw), frames_per_dispatch=depth)\n"
+        "        rgba, f32 = r.read_frame(want_float=True, slice=depth - 1)\n"
+        "        st = r.stats(); assert st.traversal_overflow == 0\n"
+        "        out += [rgba.view(np.uint32)[..., 0].astype(np.float64), f32[..., 0].astype(np.float64), f32[..., 2].astype(np.float64)]\n"
+        "        cnt += [st.rays, st.hits, st.misses, st.terminal_hits, st.tir, st.node_visits, st.tri_tests, st.pixels]\n"
+        "    r.set_tile_partition(1, 3)\n"
+        "    r.render_orbit(323, 181, 3, angle=0.3, params=rr.default_params(**kw), frames_per_dispatch=3)\n"
+        "    cnt += [r.stats().rays]\n"
+        "    r.set_tile_partition(0, 1)\n"
+        "np.save(sys.argv[1], np.stack(out)); print(' '.join(str(c) for c in cnt))\n") % ROOT
+    res = {}
+    for k, extra in (("fused", {}), ("lds", {}), ("lds", {"RR_DEBUG_SHAPE": "1"}), ("lds", {"RR_DEBUG_SHAPE": "2", "RR_DEBUG_TICKET": "19"})):
+        env = dict(os.environ, RR_DEBUG_KERNEL=k, **extra)
+        tag = k + "".join(extra.values())
+        p = subprocess.run([sys.executable, "-c", code, str(tmp_path / (tag + ".npy"))], capture_output=True, text=True, env=env, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[tag] = (np.load(tmp_path / (tag + ".npy")), p.stdout.split())
+    for tag in res:
+        assert np.array_equal(res["fused"][0], res[tag][0]), tag
+        assert res["fused"][1] == res[tag][1], tag
 
 
 def test_builds_are_deterministic(gpu):
