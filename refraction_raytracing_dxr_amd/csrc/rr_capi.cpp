@@ -822,8 +822,8 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     const char* diag_path = ctx->dbg_diag.empty() ? nullptr : ctx->dbg_diag.c_str();
     const size_t diag_waves = std::max<size_t>((size_t)a.n_blocks * 4, (size_t)ctx->n_cus * 32);
     if (diag_path && ctx->single_identity && (depth == 1 || ctx->dbg_kernel == 4)) {
-        RR_HIP(hipMalloc(&d_diag, diag_waves * 32));
-        RR_HIP(hipMemsetAsync(d_diag, 0, diag_waves * 32, ctx->stream));
+        RR_HIP(hipMalloc(&d_diag, diag_waves * 64));
+        RR_HIP(hipMemsetAsync(d_diag, 0, diag_waves * 64, ctx->stream));
         a.diag = d_diag;
     }
 
@@ -867,12 +867,14 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     // nodes read from LDS
     const MeshRes* m0 = ctx->single_identity ? &ctx->meshes[(size_t)ctx->inst_host[0].blas] : nullptr;
     const uint32_t node_bytes = m0 ? (m0->n_tris > 1 ? m0->n_tris - 1 : 1) * (uint32_t)sizeof(QNode) : 0;
-    // Worth it for launches of many slices (sphere.obj / shell.obj Depth 64: 6-7 % faster than the L1-fed kernel, whose
-    // texture addresser is 83 % busy; monkey.obj the same): a launch of few slices ends on its most expensive blocks, and
-    // there the hardware's own workgroup dispatch starts them earlier than any ticket order tried.  RR_DEBUG_KERNEL=lds
-    // forces it at every depth.
-    const bool lds_kernel = m0 && (ctx->dbg_kernel == 4 || (ctx->dbg_kernel == 0 && depth >= 32)) && ctx->dbg_stack == 0 && m0->n_tris < 32768u && 
-                            lds_kernel_shape(node_bytes, need + 1, nullptr, ctx->dbg_shape) >= 0;
+    // Worth it for launches of many slices in which the mesh fills a good part of the frame (sphere.obj / shell.obj at 1080p,
+    // Depth 64: 6 % faster than the L1-fed kernel, whose texture addresser is then 83-90 % busy; monkey.obj, whose screen
+    // rectangle is a fifth of the frame: 3 % slower -- the persistent kernel executes 6 % more vector instructions and both
+    // are bound by vector issue).  A launch of few slices ends on its most expensive blocks and pays for 768 waves sharing a
+    // ticket word: the hardware's own workgroup dispatch does better there.  RR_DEBUG_KERNEL=lds forces it wherever it fits.
+    const double rect_share = (double)(a.hx1 - a.hx0) * (double)(a.hy1 - a.hy0) / ((double)width * (double)height);
+    const bool lds_kernel = m0 && (ctx->dbg_kernel == 4 || (ctx->dbg_kernel == 0 && depth >= 32 && rect_share >= 0.25)) && ctx->dbg_stack == 0 &&
+                            m0->n_tris < 32768u && lds_kernel_shape(node_bytes, need + 1, nullptr, ctx->dbg_shape) >= 0;
     if (wavefront) RR_HIP(launch_render_wavefront(sc, a, ctx->wf, stack_sel, ctx->stream));
     else if (lds_kernel) {
         LdsDispatch q;
@@ -898,7 +900,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         if (tk == 2 || (depth > 4 && tk != 3 && tk != 1)) rect[2] = rect[0];
         // eight queues, a wave starts on its XCD's: an XCD then works on every eighth slice, which its L2 rewards
         // (monkey.obj Depth 64: 90 us per frame, 104 with 32 queues entered by wave number)
-        q.n_queues = (ctx->dbg_ticket_blocks & 16) ? LDS_QUEUES : 8u;
+        q.n_queues = (ctx->dbg_ticket_blocks & 64) ? 64u : (ctx->dbg_ticket_blocks & 128) ? LDS_QUEUES : 8u;   // launch_render_lds caps it at the grid size
         q.home_xcc = (ctx->dbg_ticket_blocks & 16) ? 0u : 1u;
         q.dbg_regpark = (ctx->dbg_ticket_blocks & 32) ? 1u : 0u;
         q.rx0 = rect[0]; q.ry0 = rect[1]; q.rx1 = rect[2]; q.ry1 = rect[3];
@@ -920,7 +922,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         ++ctx->kev_used;
     }
     if (d_diag) {       // experiments only: dump per-wave {start, cycles, max rays per lane, loop trips}
-        std::vector<unsigned long long> h(diag_waves * 4);
+        std::vector<unsigned long long> h(diag_waves * 8);
         RR_HIP(hipStreamSynchronize(ctx->stream));
         RR_HIP(hipMemcpy(h.data(), d_diag, h.size() * 8, hipMemcpyDeviceToHost));
         (void)hipFree(d_diag);

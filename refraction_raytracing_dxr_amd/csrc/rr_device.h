@@ -252,10 +252,10 @@ __device__ __forceinline__ int node_step(const BoxRay& br, const NodeQ& n, float
 }
 
 // diagnostic builds count wave-level loop trips in LDS (one word per wave); null in product builds
-struct Diag { uint32_t* trips; };      // trips[0]: internal-node trips, trips[4]: leaf trips (one word per wave each)
+struct Diag { uint32_t* trips; uint32_t stride = 4; };      // trips[0]: internal-node trips, trips[stride]: leaf trips, trips[2*stride]: shading passes (one word per wave each)
 __device__ __forceinline__ void diag_trip(const Diag& d, int which = 0)
 {
-    if (d.trips) { const unsigned long long m = __ballot(1); if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) d.trips[which * 4] += 1u; }
+    if (d.trips) { const unsigned long long m = __ballot(1); if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) d.trips[which * d.stride] += 1u; }
 }
 
 

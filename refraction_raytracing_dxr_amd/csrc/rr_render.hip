@@ -107,7 +107,7 @@ struct MemPark {
 // primary rays are Misses by construction and are not traced.
 template <bool STATS, bool TLAS, bool DIAG, class E, class NS, class PK>
 __device__ __forceinline__ f3 render_pixel(const SceneDev& sc, const DispatchDev& a, const CamDev& cb, uint32_t x, uint32_t y,
-                                           bool may_hit, E* stk, const NS ns, PK& park, LaneStats& st, uint32_t* diag_trips)
+                                           bool may_hit, E* stk, const NS ns, PK& park, LaneStats& st, const Diag dg)
 {
     f3 acc = mk3(0.0f, 0.0f, 0.0f);
     int np = 0;
@@ -122,11 +122,11 @@ __device__ __forceinline__ f3 render_pixel(const SceneDev& sc, const DispatchDev
         HitRec h;
         if (may_hit)
             trace_scene<STATS, TLAS, E, NS>(sc, O, D, tmin, tmax, outside ? CULL_BACK : CULL_FRONT, h, stk, st.cnt,
-                                            Diag{ DIAG ? diag_trips : nullptr }, ns);
+                                            DIAG ? dg : Diag{ nullptr }, ns);
         else h.hit = false;
         may_hit = true;
         ++st.rays;
-        if (DIAG) diag_trip(Diag{ diag_trips }, 2);
+        if (DIAG) diag_trip(dg, 2);
         bool have_next = false;
         if (!h.hit) {                                             // Miss
             if (STATS) ++st.miss;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, TLAS ? RR_TLAS_WAVES_PER_SIMD(STACK) : sizeof(
         st.pixels = 1;
         RegPark<PEND> park;
         const bool may_hit = DIAG || (bp.x0 + 8u > a.hx0 && bp.x0 < a.hx1 && bp.y0 + 8u > a.hy0 && bp.y0 < a.hy1);
-        const f3 acc = render_pixel<STATS, TLAS, DIAG, E, GlobalNodes>(sc, a, cb, x, y, may_hit, stk, GlobalNodes{}, park, st, &diag_trips[wave]);
+        const f3 acc = render_pixel<STATS, TLAS, DIAG, E, GlobalNodes>(sc, a, cb, x, y, may_hit, stk, GlobalNodes{}, park, st, Diag{ &diag_trips[wave], 4 });
         const size_t o = a.compact_out == 0u ? (size_t)y * a.W + x
                                             : (size_t)bp.tile_local * (TILE * TILE) + (bp.py0 + ly) * TILE + (bp.px0 + lx);
         store_pixel(a, out_rgba8, out_f32, o, acc);
@@ -293,8 +293,13 @@ template <int NW, int WGS, bool STATS, bool DIAG = false, int REGPARK = 0>
 __global__ __launch_bounds__(NW * 64, NW * WGS / 4) void k_render_lds(SceneDev sc, DispatchDev a, LdsDispatch q)
 {
     typedef uint16_t E;
+    __shared__ uint32_t diag_tr[3 * 16];        // diagnostic builds: per wave internal trips, leaf trips, shading passes
+    __shared__ uint32_t wg_arrived;             // waves of this workgroup that have finished
+    if (threadIdx.x == 0) wg_arrived = 0u;      // (ordered before its first use by the barrier behind the node copy)
     const unsigned long long diag_t0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long diag_wait = 0ull, diag_render = 0ull, diag_n = 0ull;       // cycles in ticket draws / in blocks, tickets | blocks << 32
+    unsigned long long diag_worst = 0ull, diag_worst_trips = 0ull;                // the wave's longest block: cycles, its trips (I | L << 20 | S << 40)
+    if (DIAG && threadIdx.x < 48) diag_tr[threadIdx.x] = 0;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     {   // the BLAS's nodes -> LDS (q.node_bytes is a multiple of 32)
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(sc.blas0.nodes);
@@ -302,6 +307,7 @@ __global__ __launch_bounds__(NW * 64, NW * WGS / 4) void k_render_lds(SceneDev s
         for (uint32_t i = threadIdx.x; i < q.node_bytes / 16u; i += NW * 64) dst[i] = src[i];
     }
     __syncthreads();
+    const unsigned long long diag_t1 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const LdsNodes ns{ reinterpret_cast<const char*>(lds) };
     typename std::conditional<REGPARK == 0, MemPark, RegPark<REGPARK == 0 ? 1 : REGPARK> >::type park;
@@ -313,12 +319,17 @@ __global__ __launch_bounds__(NW * 64, NW * WGS / 4) void k_render_lds(SceneDev s
     auto in_rect = [&](const BlockPos& bp) { return bp.x0 >= q.rx0 && bp.x0 < q.rx1 && bp.y0 >= q.ry0 && bp.y0 < q.ry1; };
     // The wave's work loop.  Everything that decides WHICH block comes next is wave-uniform (scalar); the renderer itself is
     // instantiated once, at the bottom of the loop (its code is ~10 KB: several inlined copies thrash the instruction cache).
-    uint32_t home = (blockIdx.x * NW + wave) % q.n_queues;
-    if (q.home_xcc) { uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); home = (xcc & 7u) % q.n_queues; }
+    // a wave's own queue: its XCD's number (queue i holds tickets i, i + n_queues, ...: with eight queues an XCD keeps to
+    // every eighth strip and slice, which its L2 rewards -- monkey.obj Depth 64, 90 us per frame against 104 with queues
+    // entered by wave number)
     const uint32_t NQ = q.n_queues;
+    uint32_t home = (blockIdx.x * NW + wave) % NQ;
+    if (q.home_xcc) { uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); home = (xcc & 7u) % NQ; }
+    const uint32_t n_chunks = (NQ + 63u) / 64u;
     uint32_t phase = 0, qi = home;
     bool stealing = false;
-    unsigned long long left = 0ull;            // queues still to drain after the wave's own
+    unsigned long long left = 0ull;            // other queues of the chunk being looked through that still hold tickets
+    uint32_t chunk = 0, chunks_seen = 0;
     BlockPos strip;                            // the phase 2 ticket in hand: a 32x8 strip, rendered as four 8x8 blocks
     uint32_t strip_j = 4u;
     for (;;) {
@@ -358,42 +369,65 @@ __global__ __launch_bounds__(NW * 64, NW * WGS / 4) void k_render_lds(SceneDev s
                     }
                     continue;
                 }
-                // this queue is empty.  The others: one look at all counters (read past the L1; they only ever grow, so a
-                // queue seen empty stays empty)
-                if (!stealing) {
-                    const uint32_t seen = lane < NQ ? __hip_atomic_load(&cnt[lane * 16u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
-                    const uint32_t mine = total > lane ? (total - lane + NQ - 1u) / NQ : 0u;
-                    left = __ballot(lane < NQ && lane != home && seen < mine);
-                    stealing = true;
+                // this queue is empty: look through the others, 64 counters at a time, starting behind the wave's own chunk
+                if (!stealing) { stealing = true; chunk = (home / 64u + 1u) % n_chunks; chunks_seen = 0; left = 0ull; }
+                while (left == 0ull && chunks_seen < n_chunks) {
+                    const uint32_t c = chunk * 64u + lane;
+                    const uint32_t seen = c < NQ ? __hip_atomic_load(&cnt[c * 16u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+                    const uint32_t theirs = total > c ? (total - c + NQ - 1u) / NQ : 0u;
+                    left = __ballot(c < NQ && c != home && seen < theirs);
+                    if (left == 0ull) { chunk = (chunk + 1u) % n_chunks; }
+                    ++chunks_seen;
                 }
-                if (left) { qi = (uint32_t)__ffsll((long long)left) - 1u; left &= left - 1ull; continue; }
+                if (left) {
+                    qi = chunk * 64u + (uint32_t)__ffsll((long long)left) - 1u;
+                    left &= left - 1ull;
+                    if (left == 0ull) chunk = (chunk + 1u) % n_chunks;
+                    continue;
+                }
             }
             ++phase; qi = home; stealing = false;
         }
         if (!have) break;
         const unsigned long long dr0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
+        const uint32_t dI0 = DIAG ? diag_tr[wave] : 0u, dL0 = DIAG ? diag_tr[16 + wave] : 0u, dS0 = DIAG ? diag_tr[32 + wave] : 0u;
         const uint32_t x = bp.x0 + lx, y = bp.y0 + ly;
         if (x < a.W && y < a.H) {
             const CamDev& cb = a.cams[bp.frame];
             st.pixels += 1;
             const bool may_hit = bp.x0 + 8u > a.hx0 && bp.x0 < a.hx1 && bp.y0 + 8u > a.hy0 && bp.y0 < a.hy1;
-            const f3 acc = render_pixel<STATS, false, false, E, LdsNodes>(sc, a, cb, x, y, may_hit, stk, ns, park, st, nullptr);
+            const f3 acc = render_pixel<STATS, false, DIAG, E, LdsNodes>(sc, a, cb, x, y, may_hit, stk, ns, park, st, Diag{ DIAG ? &diag_tr[wave] : nullptr, 16 });
             const size_t o = a.compact_out == 0u ? (size_t)y * a.W + x
                                                 : (size_t)bp.tile_local * (TILE * TILE) + (bp.py0 + ly) * TILE + (bp.px0 + lx);
             store_pixel(a, a.out_rgba8 + (size_t)bp.frame * a.frame_stride,
                         a.out_f32 ? a.out_f32 + (size_t)bp.frame * a.frame_stride : nullptr, o, acc);
         }
-        if (DIAG) { diag_render += __builtin_amdgcn_s_memtime() - dr0; diag_n += 1ull << 32; }
+        if (DIAG) {
+            const unsigned long long dt = __builtin_amdgcn_s_memtime() - dr0;
+            diag_render += dt; diag_n += 1ull << 32;
+            if (dt > diag_worst) {
+                diag_worst = dt;
+                diag_worst_trips = (unsigned long long)(diag_tr[wave] - dI0) | ((unsigned long long)(diag_tr[16 + wave] - dL0) << 20) |
+                                   ((unsigned long long)(diag_tr[32 + wave] - dS0) << 40);
+            }
+        }
     }
     if (DIAG && lane == 0) {
-        unsigned long long* d = a.diag + (size_t)(blockIdx.x * NW + wave) * 4;
+        unsigned long long* d = a.diag + (size_t)(blockIdx.x * NW + wave) * 8;
         d[0] = diag_wait; d[1] = diag_render; d[2] = diag_n; d[3] = __builtin_amdgcn_s_memtime() - diag_t0;
+        d[4] = diag_worst; d[5] = diag_worst_trips; d[6] = diag_t1 - diag_t0; d[7] = diag_tr[wave] | ((unsigned long long)diag_tr[16 + wave] << 32);
     }
     flush_stats<STATS>(a, st, blockIdx.x * NW + wave, lane);
-    if (lane == 0) {        // every ticket this wave drew came back before this add: the last arrival sees all queues drained
-        const uint32_t arrived = atomicAdd(&q.tickets[2u * LDS_QUEUES * 16u], 1u);
-        if (arrived + 1u == gridDim.x * NW) {
-            for (uint32_t k = 0; k <= 2u * LDS_QUEUES; ++k) atomicExch(&q.tickets[k * 16u], 0u);
+    // Every ticket a wave drew came back before it arrives here, so the last workgroup to arrive sees all queues drained and
+    // zeroes the words for the next launch.  One arrival per workgroup (its waves count in LDS first): one per wave would be
+    // 6 144 atomics on one word.
+    if (lane == 0) {
+        const uint32_t w_arrived = atomicAdd(&wg_arrived, 1u);
+        if (w_arrived + 1u == (uint32_t)NW) {
+            const uint32_t arrived = atomicAdd(&q.tickets[2u * LDS_QUEUES * 16u], 1u);
+            if (arrived + 1u == gridDim.x) {
+                for (uint32_t k = 0; k <= 2u * LDS_QUEUES; ++k) atomicExch(&q.tickets[k * 16u], 0u);
+            }
         }
     }
 }
@@ -903,8 +937,8 @@ template <int NW, int WGS>
 static hipError_t launch_lds_nw(const SceneDev& sc, const DispatchDev& a, const LdsDispatch& q, size_t lds, int n_cus, bool stats, hipStream_t s)
 {
     static const hipError_t attr = [] {       // more than 64 KB of dynamic LDS has to be asked for, once per instantiation
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_lds<NW, WGS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_lds<NW, WGS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_lds<NW, WGS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_lds<NW, WGS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
         return e;
     }();
     if (attr != hipSuccess) return attr;
@@ -936,6 +970,13 @@ hipError_t launch_render_lds(const SceneDev& sc, const DispatchDev& a, LdsDispat
     const int shape = lds_kernel_shape(q.node_bytes, q.stack_entries, &lds, min_shape);
     if (shape < 0) return hipErrorInvalidValue;
     q.wave_blocks = a.n_blocks * 4u;
+    {   // one queue per workgroup of the shape that will run (never more than LDS_QUEUES)
+        static const int wgs[] = { 2, 2, 1 };
+        const uint32_t grid = (uint32_t)n_cus * (uint32_t)wgs[shape];
+        if (q.n_queues > grid) q.n_queues = grid;
+        if (q.n_queues > LDS_QUEUES) q.n_queues = LDS_QUEUES;
+        if (q.n_queues < 1u) q.n_queues = 1u;
+    }
     q.p2_strips = 1u;
     q.p2_tickets = a.n_blocks;                  // one 32x8 strip (four wave-blocks) per ticket
     const bool rect = q.rx1 > q.rx0 && q.ry1 > q.ry0;
@@ -943,14 +984,14 @@ hipError_t launch_render_lds(const SceneDev& sc, const DispatchDev& a, LdsDispat
     q.p1_direct = (a.compact_out == 0u && a.tile_world == 1u) ? 1u : 0u;
     q.p1_tickets = !rect ? 0u : q.p1_direct ? q.rect_bw * ((q.ry1 - q.ry0) / 8u) * a.n_frames : q.wave_blocks;
     if (a.diag) {       // diagnostic build (RR_DEBUG_DIAG): per-wave cycles in ticket draws and in blocks; 12x2 shape
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_lds<12, 2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_lds<12, 2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
         if (attr != hipSuccess) return attr;
         const size_t l12 = (size_t)q.node_bytes + (size_t)12 * q.stack_entries * 64 * sizeof(uint16_t);
         hipLaunchKernelGGL((k_render_lds<12, 2, false, true>), dim3((uint32_t)n_cus * 2), dim3(12 * 64), l12, s, sc, a, q);
         return hipGetLastError();
     }
     if (q.dbg_regpark && shape == 1 && q.park_slots <= 2u && !stats) {      // experiment: parked rays in registers
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_lds<16, 2, false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_lds<16, 2, false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
         if (attr != hipSuccess) return attr;
         hipLaunchKernelGGL((k_render_lds<16, 2, false, false, 2>), dim3((uint32_t)n_cus * 2), dim3(16 * 64), lds, s, sc, a, q);
         return hipGetLastError();

@@ -152,10 +152,15 @@ struct LdsDispatch {
     uint32_t node_bytes;        // size of the node array copied to LDS (multiple of 32)
     uint32_t stack_entries;     // per-lane traversal stack entries (> tree depth)
 };
-// Ticket counters: one word saturates near 88 dequeues per microsecond (MI355X_MICROARCH.md "dequeue") and 8 192 waves pull
-// from them, so each phase has LDS_QUEUES of them (ticket u belongs to queue u % LDS_QUEUES); a wave starts on the queue
-// of its own number and, once that is empty, reads all counters with one load and drains whichever are not.
-constexpr uint32_t LDS_QUEUES = 32;
+// Ticket counters: ticket u belongs to queue u % n_queues; a wave starts on the queue of its XCD's number and, once that
+// is empty, looks through the other counters 64 at a time (plain loads past the L1: a counter only ever grows, so a queue
+// seen empty stays empty) and drains those that are not.  Eight queues are the product setting: an XCD then keeps to every
+// eighth strip and slice, which its L2 rewards, and k_render_lds is only used for launches of 32 slices and more, where the
+// cost of 768 waves sharing a word does not show (a word takes about 88 returning atomics per microsecond under a few
+// contenders, MI355X_MICROARCH.md "dequeue", far fewer under hundreds: a Depth-1 launch of primary rays alone takes 294 us
+// with 8 queues, 132 with 32, 107 with 64 -- and 58 with k_render_fused, which the hardware dispatcher feeds and which
+// therefore renders the launches of few slices).  RR_DEBUG_TICKET +64 / +128 select 64 / 512 queues for experiments.
+constexpr uint32_t LDS_QUEUES = 512;
 constexpr uint32_t LDS_TICKET_WORDS = (2 * LDS_QUEUES + 1) * 16;
 
 enum Counter : int {

@@ -10,9 +10,8 @@ from refraction_raytracing_dxr_amd.synth import asset, procedural_env
 W, H = 1920, 1080
 env = procedural_env(2048, 1024, seed=0)
 cases = [c.split(":") for c in (sys.argv[1:] or ["monkey.obj:8", "sphere.obj:4", "shell.obj:5"])]
-for kern, envv in (("fused", {"RR_DEBUG_KERNEL": "fused"}), ("lds 16x2", {}), ("lds 16x2 q8xcc", {"RR_DEBUG_TICKET": "16"}),
-                  ("lds 16x2 regpark", {"RR_DEBUG_TICKET": "32"}), ("lds 16x2 q8xcc regpark", {"RR_DEBUG_TICKET": "48"}),
-                  ("lds 12x2", {"RR_DEBUG_SHAPE": "1"}), ("lds 12x2 q8xcc", {"RR_DEBUG_SHAPE": "1", "RR_DEBUG_TICKET": "16"})):
+for kern, envv in (("fused", {"RR_DEBUG_KERNEL": "fused"}), ("lds q8", {"RR_DEBUG_KERNEL": "lds"}), ("lds q64", {"RR_DEBUG_KERNEL": "lds", "RR_DEBUG_TICKET": "64"}),
+                   ("lds q512", {"RR_DEBUG_KERNEL": "lds", "RR_DEBUG_TICKET": "128"})):
     for k in ("RR_DEBUG_KERNEL", "RR_DEBUG_TICKET", "RR_DEBUG_SHAPE"): os.environ.pop(k, None)
     os.environ.update(envv)
     r = rr.Renderer(0)
