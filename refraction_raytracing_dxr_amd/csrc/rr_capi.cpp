@@ -344,7 +344,7 @@ int rr_create(int device_ordinal, rr_context** out)
     (void)hipMemsetAsync(ctx->d_cnt, 0, sizeof(CounterBlock), ctx->stream);
     (void)hipMemsetAsync(ctx->d_tickets, 0, (rr_context::MAX_LANES + 1) * LDS_TICKET_WORDS * sizeof(uint32_t), ctx->stream);   // the kernel leaves them zero
     if (const char* e = getenv("RR_DEBUG_KERNEL"))
-        ctx->dbg_kernel = !strcmp(e, "fused") ? 1 : !strcmp(e, "async") ? 2 : !strcmp(e, "wavefront") ? 3 : !strcmp(e, "lds") ? 4 : 0;
+        ctx->dbg_kernel = !strcmp(e, "fused") ? 1 : !strcmp(e, "async") ? 2 : !strcmp(e, "wavefront") ? 3 : !strcmp(e, "lds") ? 4 : !strcmp(e, "paths") ? 5 : 0;
     if (const char* e = getenv("RR_DEBUG_STACK")) ctx->dbg_stack = atoi(e);
     if (const char* e = getenv("RR_DEBUG_TICKET")) ctx->dbg_ticket_blocks = atoi(e);
     if (const char* e = getenv("RR_DEBUG_SHAPE")) ctx->dbg_shape = atoi(e);
@@ -867,15 +867,25 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     // nodes read from LDS
     const MeshRes* m0 = ctx->single_identity ? &ctx->meshes[(size_t)ctx->inst_host[0].blas] : nullptr;
     const uint32_t node_bytes = m0 ? (m0->n_tris > 1 ? m0->n_tris - 1 : 1) * (uint32_t)sizeof(QNode) : 0;
+    // share of the frame in which the scene can be seen at all in these slices
+    const double rect_share = (double)(a.hx1 - a.hx0) * (double)(a.hy1 - a.hy0) / ((double)width * (double)height);
     // Worth it for launches of many slices in which the mesh fills a good part of the frame (sphere.obj / shell.obj at 1080p,
     // Depth 64: 6 % faster than the L1-fed kernel, whose texture addresser is then 83-90 % busy; monkey.obj, whose screen
     // rectangle is a fifth of the frame: 3 % slower -- the persistent kernel executes 6 % more vector instructions and both
     // are bound by vector issue).  A launch of few slices ends on its most expensive blocks and pays for 768 waves sharing a
     // ticket word: the hardware's own workgroup dispatch does better there.  RR_DEBUG_KERNEL=lds forces it wherever it fits.
-    const double rect_share = (double)(a.hx1 - a.hx0) * (double)(a.hy1 - a.hy0) / ((double)width * (double)height);
     const bool lds_kernel = m0 && (ctx->dbg_kernel == 4 || (ctx->dbg_kernel == 0 && depth >= 32 && rect_share >= 0.25)) && ctx->dbg_stack == 0 &&
                             m0->n_tris < 32768u && lds_kernel_shape(node_bytes, need + 1, nullptr, ctx->dbg_shape) >= 0;
+    // Launches of one or two slices whose scene is small on screen last as long as their most expensive wave: there the
+    // path-parallel kernel (four lanes per pixel inside the scene's screen rectangle: a fifth of the longest chain of
+    // dependent rays, four waves per block) wins -- monkey.obj 1080p Depth 1: 268 us against 471, ott.obj 626 against 1 419.
+    // It traces the primary ray four times and the count-1 rays twice, so where the mesh fills the frame and the launch is
+    // bound by throughput it loses (sphere.obj 483 us against 263, shell.obj 606 against 348): those stay with k_render_fused.
+    const bool have_rect = a.hx1 > a.hx0 && a.hy1 > a.hy0;
+    const bool paths_kernel = (ctx->dbg_kernel == 5 || (ctx->dbg_kernel == 0 && depth <= 2 && rect_share < 0.25)) && !compact && ctx->tile_world == 1 &&
+                              p.max_reflect <= 2 && need <= 39 && !a.diag && ctx->dbg_stack == 0 && have_rect;
     if (wavefront) RR_HIP(launch_render_wavefront(sc, a, ctx->wf, stack_sel, ctx->stream));
+    else if (paths_kernel) RR_HIP(launch_render_paths(sc, a, (int)need, stats, ctx->stream));
     else if (lds_kernel) {
         LdsDispatch q;
         memset(&q, 0, sizeof q);

@@ -276,6 +276,126 @@ __global__ __launch_bounds__(256, TLAS ? RR_TLAS_WAVES_PER_SIMD(STACK) : sizeof(
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Path-parallel form, for launches of one or two slices (the reference's own shape is DispatchRays(W,H,1),
+// RefractionDemo.cpp:589-594).  Such a launch lasts as long as its most expensive wave: in k_render_fused a lane walks its
+// pixel's whole ray tree, up to 19 rays one after the other on monkey.obj, and the wave that owns that pixel makes 1 400
+// loop trips while the rest of the chip is idle (Depth 1: 460 us per frame against 82 at Depth 64).  The tree only
+// branches while count < max_reflect; for max_reflect <= 2 it therefore has at most four root-to-leaf paths -- refract or
+// reflect at the primary hit, refract or reflect at the next, refractions only from there on -- and each ends in at most
+// one leaf (a Miss, weight * texel; a terminal hit or a total internal reflection ends it with nothing).  Here FOUR lanes
+// share a pixel, lane p following path p (bit 1: reflect at count 0, bit 0: reflect at count 1); the four leaves are then
+// summed in the recursion's order -- TT, TR, RT, RR, the order in which k_render_fused reaches them -- with the same
+// fma sequence, a path without a leaf contributing fma(0, 0, acc) = acc.  So the frame is bit-identical, the longest chain of
+// dependent rays drops from 19 to 2 + the refraction limit, and a block's work spreads over four waves.  The primary ray is
+// traced by all four lanes and the two count-1 rays by two each (more work, which a launch of one slice has room for);
+// counters count a shared ray once.
+// A workgroup is an 8x8 pixel block inside the scene's screen rectangle (its four waves take the 4x4 quadrants); the blocks
+// outside the rectangle follow in the same launch as 32x8 strips, one Miss per pixel without a trace.
+struct PathLeaf { float w; f3 e; };
+
+template <bool STATS, bool TLAS, class E>
+__device__ __forceinline__ PathLeaf render_path(const SceneDev& sc, const DispatchDev& a, const CamDev& cb, uint32_t x, uint32_t y,
+                                                uint32_t path, E* stk, LaneStats& st)
+{
+    PathLeaf leaf; leaf.w = 0.0f; leaf.e = mk3(0.0f, 0.0f, 0.0f);
+    f3 O = mk3(cb.cam[0], cb.cam[1], cb.cam[2]);
+    f3 D = camera_ray_dir(cb.M, a.sx[x], a.sy[y]);
+    float w = 1.0f;
+    uint32_t count = 0;
+    bool outside = true;
+    float tmin = a.tmin_p, tmax = a.tmax_p;
+    for (;;) {
+        // the lane that accounts for this ray (and owns its leaf, should it be one): rays at count 0 are shared by the four
+        // lanes of the pixel, rays at count 1 by the two with the same first turn
+        const bool owner = count == 0u ? path == 0u : count == 1u ? (path & 1u) == 0u : true;
+        HitRec h;
+        TravCounters cnt; cnt.nodes = 0; cnt.tris = 0;
+        trace_scene<STATS, TLAS, E, GlobalNodes>(sc, O, D, tmin, tmax, outside ? CULL_BACK : CULL_FRONT, h, stk, cnt);
+        if (owner) { ++st.rays; if (STATS) { st.cnt.nodes += cnt.nodes; st.cnt.tris += cnt.tris; } }
+        if (!h.hit) {                                             // Miss
+            if (owner) { if (STATS) ++st.miss; leaf.w = w; leaf.e = env_lookup(sc, D); }
+            break;
+        }
+        if (STATS && owner) ++st.hits;
+        if ((int)count >= a.max_refract) { if (STATS && owner) ++st.term; break; }      // hlsl:82, payload.color stays 0
+        const f3 N = shading_normal<TLAS>(sc, h);
+        const f3 X = mk3(fmaf(h.t, D.x, O.x), fmaf(h.t, D.y, O.y), fmaf(h.t, D.z, O.z));
+        const f3 Nf = outside ? N : neg3(N);
+        const float R0 = (0.2f / 2.2f) * (0.2f / 2.2f);
+        const float b = 1.0f - dot3(D, Nf);
+        const float b2 = b * b, b4 = b2 * b2;
+        const float R = (R0 * (1.0f - R0)) * (b4 * b);
+        const float eta = outside ? a.inv_ior : a.ior;
+        f3 d1;
+        const bool refr = refract_ray(d1, D, Nf, eta);
+        if (STATS && owner && !refr) ++st.tir;
+        const bool refl = (int)count < a.max_reflect;
+        // which child this lane follows: the reflected one where its path says so (count 0: bit 1, count 1: bit 0), else the
+        // refracted one; k_render_fused follows the refracted child and parks the reflected one, or, without a refracted
+        // child, follows the reflected one directly -- that one is then the node's only subtree, and it belongs to the
+        // "reflect" lanes here as well (the "refract" lanes have no leaf below this node)
+        const bool turn = count == 0u ? (path & 2u) != 0u : count == 1u ? (path & 1u) != 0u : false;
+        const uint32_t c1 = count + 1u;
+        tmin = a.tmin_s; tmax = a.tmax_s;
+        O = X;
+        if (!turn) {
+            if (!refr) break;
+            D = d1; w = w * (1.0f - R); count = c1; outside = !outside;
+        } else {
+            if (!refl) break;
+            D = normalize3(reflect_ray(D, Nf)); w = w * R; count = c1;
+        }
+    }
+    return leaf;
+}
+
+template <int STACK, bool STATS, bool TLAS>
+__global__ __launch_bounds__(256, 8) void k_render_paths(SceneDev sc, DispatchDev a, uint32_t n_pp_blocks, uint32_t rect_bw)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    LaneStats st;
+    if (blockIdx.x < n_pp_blocks) {
+        uint32_t* stk = lds + wave * (STACK * 64) + lane;
+        const uint32_t frame = blockIdx.x % a.n_frames, b = blockIdx.x / a.n_frames;
+        const uint32_t x0 = a.hx0 + (b % rect_bw) * 8u + (wave & 1u) * 4u, y0 = a.hy0 + (b / rect_bw) * 8u + (wave >> 1) * 4u;
+        const uint32_t pix = lane >> 2, path = lane & 3u;
+        const uint32_t x = x0 + (pix & 3u), y = y0 + (pix >> 2);
+        const bool valid = x < a.W && y < a.H;
+        PathLeaf lf; lf.w = 0.0f; lf.e = mk3(0.0f, 0.0f, 0.0f);
+        if (valid) {
+            if (path == 0u) st.pixels = 1;
+            lf = render_path<STATS, TLAS, uint32_t>(sc, a, a.cams[frame], x, y, path, stk, st);
+        }
+        // the pixel's colour: its leaves in the recursion's order (lanes 4*pix .. 4*pix+3)
+        f3 acc = mk3(0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int src = (int)(lane & ~3u) + p;
+            const float w = __shfl(lf.w, src, 64), ex = __shfl(lf.e.x, src, 64), ey = __shfl(lf.e.y, src, 64), ez = __shfl(lf.e.z, src, 64);
+            acc.x = fmaf(w, ex, acc.x); acc.y = fmaf(w, ey, acc.y); acc.z = fmaf(w, ez, acc.z);
+        }
+        if (valid && path == 0u)
+            store_pixel(a, a.out_rgba8 + (size_t)frame * a.frame_stride, a.out_f32 ? a.out_f32 + (size_t)frame * a.frame_stride : nullptr,
+                        (size_t)y * a.W + x, acc);
+    } else {                                                       // a 32x8 strip outside the rectangle: Miss only
+        const BlockPos bp = wave_block_pos(a, (blockIdx.x - n_pp_blocks) * 4u + wave);
+        const uint32_t x = bp.x0 + compact1by1(lane), y = bp.y0 + compact1by1(lane >> 1);
+        const bool in_rect = bp.x0 >= a.hx0 && bp.x0 < a.hx1 && bp.y0 >= a.hy0 && bp.y0 < a.hy1;
+        if (bp.tile_ok && !in_rect && x < a.W && y < a.H) {
+            const CamDev& cb = a.cams[bp.frame];
+            const f3 D = camera_ray_dir(cb.M, a.sx[x], a.sy[y]);
+            st.pixels = 1; st.rays = 1; if (STATS) st.miss = 1;
+            const f3 e = env_lookup(sc, D);
+            const f3 acc = mk3(fmaf(1.0f, e.x, 0.0f), fmaf(1.0f, e.y, 0.0f), fmaf(1.0f, e.z, 0.0f));
+            store_pixel(a, a.out_rgba8 + (size_t)bp.frame * a.frame_stride, a.out_f32 ? a.out_f32 + (size_t)bp.frame * a.frame_stride : nullptr,
+                        (size_t)y * a.W + x, acc);
+        }
+    }
+    flush_stats<STATS>(a, st, blockIdx.x * 4u + wave, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // The same renderer with the BLAS's nodes in LDS, for meshes whose whole node array fits beside the traversal stacks
 // (the reference's meshes up to shell.obj: 24-49 KB of QNodes).  Persistent workgroups of NW waves: each copies the node
 // array into its LDS once, then every wave pulls 8x8 pixel blocks (wave-blocks, numbered exactly as k_render_fused's) from
@@ -1053,6 +1173,25 @@ hipError_t launch_trace_rays(const SceneDev& sc, const rr_ray_dev* rays, uint32_
     if (stack <= 31) { if (sc.single_identity) launch_trace_st<31, false>(sc, rays, n, hits, err, s); else launch_trace_st<31, true>(sc, rays, n, hits, err, s); }
     else             { if (sc.single_identity) launch_trace_st<64, false>(sc, rays, n, hits, err, s); else launch_trace_st<64, true>(sc, rays, n, hits, err, s); }
     return hipGetLastError();
+}
+
+template <int STACK, bool TLAS>
+static hipError_t launch_paths_st(const SceneDev& sc, const DispatchDev& a, uint32_t n_pp, uint32_t rect_bw, bool stats, hipStream_t s)
+{
+    const size_t lds = (size_t)4 * STACK * 64 * sizeof(uint32_t);
+    const dim3 grid(n_pp + a.n_blocks);
+    if (stats) hipLaunchKernelGGL((k_render_paths<STACK, true, TLAS>), grid, dim3(256), lds, s, sc, a, n_pp, rect_bw);
+    else       hipLaunchKernelGGL((k_render_paths<STACK, false, TLAS>), grid, dim3(256), lds, s, sc, a, n_pp, rect_bw);
+    return hipGetLastError();
+}
+
+// unsharded raster frames, max_reflect <= 2, stack <= 39 entries; the rectangle DispatchDev::hx0..hy1 is not empty
+hipError_t launch_render_paths(const SceneDev& sc, const DispatchDev& a, int stack, bool stats, hipStream_t s)
+{
+    const uint32_t rect_bw = (a.hx1 - a.hx0) / 8u, rect_bh = (a.hy1 - a.hy0) / 8u;
+    const uint32_t n_pp = rect_bw * rect_bh * a.n_frames;
+    if (!sc.single_identity) return stack <= 19 ? launch_paths_st<19, true>(sc, a, n_pp, rect_bw, stats, s) : launch_paths_st<39, true>(sc, a, n_pp, rect_bw, stats, s);
+    return stack <= 19 ? launch_paths_st<19, false>(sc, a, n_pp, rect_bw, stats, s) : launch_paths_st<39, false>(sc, a, n_pp, rect_bw, stats, s);
 }
 
 hipError_t launch_screen_tables(float* out, uint32_t W, uint32_t H, hipStream_t s)

@@ -273,9 +273,9 @@ def test_experimental_wavefront_kernels_render_the_same_frames(tmp_path):
     assert res["fused"][1] == res["wavefront"][1]                      # and the same number of TraceRay calls
 
 
-def test_lds_kernel_renders_the_same_frames(tmp_path):
-    """k_render_lds (persistent workgroups, BLAS nodes in LDS, tickets, reflected rays parked in memory) against
-    k_render_fused and against the oracle: every frame byte for byte, float colours bit for bit, the same counters --
+def test_lds_and_path_parallel_kernels_render_the_same_frames(tmp_path):
+    """k_render_lds (persistent workgroups, BLAS nodes in LDS, tickets, reflected rays parked in memory) and k_render_paths
+    (four lanes per pixel, one per root-to-leaf path of the ray tree) against k_render_fused: every frame byte for byte, float colours bit for bit, the same counters --
     at Depth 1 (mesh rectangle first), Depth 5 / 40 (image order), with float output, with stats, sharded tiles (the
     scan form of the ticket order) and for each workgroup shape.  Own processes: the switches are read at rr_create."""
     import subprocess
@@ -301,7 +301,8 @@ def test_lds_kernel_renders_the_same_frames(tmp_path):
         "    r.set_tile_partition(0, 1)\n"
         "np.save(sys.argv[1], np.stack(out)); print(' '.join(str(c) for c in cnt))\n") % ROOT
     res = {}
-    for k, extra in (("fused", {}), ("lds", {}), ("lds", {"RR_DEBUG_SHAPE": "1"}), ("lds", {"RR_DEBUG_SHAPE": "2", "RR_DEBUG_TICKET": "19"})):
+    for k, extra in (("fused", {}), ("lds", {}), ("lds", {"RR_DEBUG_SHAPE": "1"}), ("lds", {"RR_DEBUG_SHAPE": "2", "RR_DEBUG_TICKET": "19"}),
+                     ("paths", {})):            # k_render_paths: four lanes per pixel, leaves summed in the recursion's order
         env = dict(os.environ, RR_DEBUG_KERNEL=k, **extra)
         tag = k + "".join(extra.values())
         p = subprocess.run([sys.executable, "-c", code, str(tmp_path / (tag + ".npy"))], capture_output=True, text=True, env=env, timeout=600)

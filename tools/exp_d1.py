@@ -7,7 +7,7 @@ import refraction_raytracing_dxr_amd as rr
 from refraction_raytracing_dxr_amd.synth import asset, procedural_env
 name = sys.argv[1] if len(sys.argv) > 1 else "monkey.obj"
 env = procedural_env(2048, 1024, seed=0)
-for kern, envv in (("fused", {"RR_DEBUG_KERNEL": "fused"}), ("lds", {"RR_DEBUG_KERNEL": "lds"}), ("lds q64", {"RR_DEBUG_KERNEL": "lds", "RR_DEBUG_TICKET": "128"}), ("lds q512wave", {"RR_DEBUG_KERNEL": "lds", "RR_DEBUG_TICKET": "16"})):
+for kern, envv in (("fused", {"RR_DEBUG_KERNEL": "fused"}), ("paths", {"RR_DEBUG_KERNEL": "paths"}), ("lds", {"RR_DEBUG_KERNEL": "lds"})):
     for k in ("RR_DEBUG_KERNEL", "RR_DEBUG_TICKET", "RR_DEBUG_SHAPE"): os.environ.pop(k, None)
     os.environ.update(envv)
     r = rr.Renderer(0)
