@@ -28,6 +28,21 @@ W, H = 1920, 1080
 MAX_REFRACT, MAX_REFLECT = 8, 2
 ENV_W, ENV_H = 2048, 1024
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+N_SIMD, CLOCK_GHZ = 1024, 2.4    # 256 CUs x 4 SIMD-32, 2.4 GHz max clock (MI355X_MICROARCH.md)
+# Vector-issue roofline of k_render_fused<19, 2, false, false> (the kernel the headline workload runs on).  The kernel is
+# bound by vector (VALU) issue: the SIMDs hold 8 waves each and every traversal instruction but the f32 add / mul / fma is a
+# quarter-rate one on gfx950 (tools/ubench_valu.hip, profiles/r02_ubench_valu.txt: v_fma_f32 / v_mul_f32 2.2 cycles per
+# wave64 instruction per SIMD, v_cndmask / v_fma_mix_f32 / v_max3 / v_min / v_cmp / v_bfi 4.2, transcendental 8).  A 64-lane
+# wave issues one internal-node step, one triangle test or one shading pass per loop trip however many lanes take part, so
+# its issue time is  node_trips * C_NODE + leaf_trips * C_LEAF + shade_passes * C_PASS + waves * C_WAVE  SIMD cycles, with
+# per-trip instruction counts fitted against the PMC counters SQ_INSTS_VALU / _ADD_F32 / _MUL_F32 / _FMA_F32 / _TRANS_F32
+# of six workloads (tools/fit_valu.sh, tools/fit_valu.py; residual <= 0.2 %, profiles/r02_valu_fit.txt) and priced with the
+# class costs above.  The trip counters are exact and come from the RR_DISPATCH_COLLECT_STATS launches of the same frames.
+VALU_CYCLES_PER_TRIP = {"node": 30.9 * 4.2,                               # 30.9 instructions, all quarter rate (12 of them v_fma_mix_f32)
+                        "leaf": 30.9 * 2.2 + 27.9 * 4.2 + 0.4 * 8.0,      # 59.2: Moller-Trumbore is mostly f32 mul / fma
+                        "pass": 117.9 * 2.2 + 111.3 * 4.2 + 10.1 * 8.0,   # 239.2 per shading pass (ray set-up, ClosestHit / Miss)
+                        "wave": 111.4 * 4.2}                              # per 8x8 block: RayGen, addressing, store
+ROOFLINE_KERNEL = "k_render_fused<19, 2, false, false, false, unsigned int>"
 
 
 def algorithmic_bytes(st):
@@ -43,6 +58,67 @@ def algorithmic_bytes(st):
 def survey_formula_bytes(st):
     return (64 * st.node_visits + 48 * st.tri_tests + 96 * st.secondary + 36 * st.hits + 12 * st.misses
             + 16 * st.pixels)
+
+
+def valu_issue_cycles(st):
+    c = VALU_CYCLES_PER_TRIP
+    return st.node_trips * c["node"] + st.leaf_trips * c["leaf"] + st.shade_passes * c["pass"] + st.waves * c["wave"]
+
+
+def xf(tx, ty, tz, s=1.0):
+    m = np.eye(4, dtype=np.float32)[:3] * np.float32(s)
+    m[:, 3] = (tx, ty, tz)
+    return m
+
+
+def config_records(r, rr, asset, env):
+    """The other BASELINE.json configurations on this GPU (C1, C2, C4, C5; C3 is the headline): HIP-event kernel time of
+    16-slice launches and of single launches, exact ray counts.  Scene placement of C4 / C5 as in SURVEY 8d (builder-defined:
+    the reference has one mesh, one instance)."""
+    def load(n):
+        m = rr.Mesh(); assert m.load(asset(n)); return m
+    cases = [
+        ("C1", "sphere.obj 256x256, 1 refraction bounce", ["sphere.obj"], None, 256, 256, 1, 1.0),
+        ("C2", "sphere.obj 1920x1080, 4 refraction bounces", ["sphere.obj"], None, 1920, 1080, 4, 1.0),
+        ("C4", "shell.obj + cube.obj + ott.obj (3 BLAS, TLAS) 3840x2160, 8 bounces", ["shell.obj", "cube.obj", "ott.obj"],
+         ([xf(0, 0, 0), xf(0, 0, -4.0), xf(0, 0, 4.0)], [0, 1, 2]), 3840, 2160, 8, 1.6),
+        ("C5", "monkey.obj x 1024 instances (TLAS) 3840x2160, 16 bounces", ["monkey.obj"],
+         ([xf(3.0 * (i - 15.5), 0, 3.0 * (j - 15.5)) for i in range(32) for j in range(32)], [0] * 1024), 3840, 2160, 16, 14.0),
+    ]
+    out = {}
+    for key, label, names, inst, W_, H_, refr, radius in cases:
+        ids = []
+        for m in [load(n) for n in names]:
+            mid = r.upload_mesh(m.verts, m.indices); r.build_blas(mid); ids.append(mid)
+        if inst is None:
+            r.build_tlas(rr.make_instances(meshes=[ids[0]]))
+        else:
+            r.build_tlas(rr.make_instances(transforms=inst[0], meshes=[ids[k] for k in inst[1]]))
+        r.upload_envmap(env)
+        cams = []
+        for k in range(16):
+            sc = rr.camera_orbit(0.01 * (k + 1))
+            sc.camera_loc[0] *= radius; sc.camera_loc[2] *= radius
+            if radius > 2: sc.camera_loc[1] = 0.8 * radius
+            cams.append(sc)
+        rec = {"workload": label}
+        for depth in (16, 1):
+            p = rr.default_params(max_refract=refr, flags=rr.DISPATCH_TIME_KERNEL)
+            for rep in range(3):
+                if depth == 1:
+                    for c in cams[:4]:
+                        r.set_camera(c); r.dispatch_rays(W_, H_, p)
+                else:
+                    r.dispatch_rays_batch(W_, H_, cams, p)
+                if rep == 0: r.kernel_time()
+            ms, n = r.kernel_time()
+            st = r.stats()
+            frames = 1 if depth == 1 else 16
+            us = ms / n * 1e3 / frames
+            rec["depth%d" % depth] = {"us_per_frame": round(us, 1), "Mrays_per_s": round(st.rays / frames / us, 1),
+                                      "rays_per_frame": int(st.rays / frames)}
+        out[key] = rec
+    return out
 
 
 def host_cores():
@@ -88,7 +164,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12288)     # 1.3 s of frames on one GPU: the timed region is not launch jitter
     ap.add_argument("--warmup", type=int, default=192)      # three launches: both render lanes and all three buffer sets of the N>1 pipeline
-    ap.add_argument("--depth1", action="store_true", help="also time the reference's shape, one DispatchRays per frame")
+    ap.add_argument("--no-depth1", action="store_true", help="skip the reference's own shape, one DispatchRays per frame (32 launches, ~15 ms)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the single-GPU records of the other BASELINE configurations (C1, C2, C4, C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-subdiv", action="store_true",
                     help="skip the second figure (15 472-triangle monkey); profiling runs use this so that every "
@@ -184,44 +261,70 @@ def main():
     roofline = None
     cpu = None
     subdiv = None
+    configs = None
+    Fl = min(K, F)                  # slices per launch as the timed region really issued them
     if rank == 0:
         r.set_tile_partition(0, 1)
-        # whole launches of F consecutive frames, their start angles spread over the timed orbit (consecutive frames
+        # whole launches of Fl consecutive frames, their start angles spread over the timed orbit (consecutive frames
         # share cache lines, so a launch must hold consecutive frames to be a launch of the timed loop)
-        n_launch = max(1, min(K, 512) // F)
-        n_prof = n_launch * F
+        n_launch = max(1, min(K, 512) // Fl)
         starts = [0.01 + 0.01 * ((K // n_launch) * j) for j in range(n_launch)]
         for flag in (rr.DISPATCH_COLLECT_STATS, rr.DISPATCH_TIME_KERNEL):
             for j, a0 in enumerate(starts):
-                r.render_orbit(W, H, F, angle=a0, frames_per_dispatch=F, params=rr.default_params(
+                r.render_orbit(W, H, Fl, angle=a0, frames_per_dispatch=Fl, params=rr.default_params(
                     max_refract=MAX_REFRACT, max_reflect=MAX_REFLECT, flags=flag | (rr.DISPATCH_KEEP_COUNTERS if j else 0)))
             if flag == rr.DISPATCH_COLLECT_STATS:
-                sst = r.stats()                                             # exact counters, summed over n_prof frames
+                sst = r.stats()                                             # exact counters, summed over the n_launch launches
         kms, kn = r.kernel_time()                                           # HIP events around each launch, on the launch stream
-        bytes_per_launch = algorithmic_bytes(sst) / kn                      # one launch = F frames
         kernel_us = kms / kn * 1e3
+        render_kernel = int(r.stats().render_kernel)                        # which kernel those launches were
         k1ms, k1n = None, 0
-        if args.depth1:   # the reference's own shape, one DispatchRays per frame (Depth 1), for comparison
+        if not args.no_depth1:   # the reference's own shape, one DispatchRays per frame (RefractionDemo.cpp:589-594: Depth = 1)
             r.render_orbit(W, H, 32, angle=0.01, frames_per_dispatch=1, params=rr.default_params(
                 max_refract=MAX_REFRACT, max_reflect=MAX_REFLECT, flags=rr.DISPATCH_TIME_KERNEL))
             k1ms, k1n = r.kernel_time()
-        achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
+        # vector-issue roofline: SIMD cycles the launch's wave-level trips need / SIMD cycles the launch had
+        issue_cycles = valu_issue_cycles(sst) / kn
+        achieved = issue_cycles / (kernel_us * 1e-6) / 1e9                  # G SIMD-cycles of vector issue per second
+        peak = N_SIMD * CLOCK_GHZ
+        frac = achieved / peak
+        if not frac <= 1.0:
+            raise SystemExit("roofline: vector-issue fraction %.3f > 1 -- the per-trip costs no longer describe the kernel; refit "
+                             "(tools/fit_valu.sh) before reporting" % frac)
+        bytes_per_launch = algorithmic_bytes(sst) / kn
         traffic = None
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))      # the latest round's PMC passes
-        tpath = cands[-1] if cands else ""
-        if tpath:
+        if cands:
             try:
-                tj = json.load(open(tpath))
-                if tj.get("frames_per_launch") == F:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                tj = json.load(open(cands[-1]))
+                traffic = {"hbm_bytes_per_launch": tj.get("hbm_bytes_per_launch"), "frames_per_launch": tj.get("frames_per_launch"),
+                           "source": "static: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command), not measured in this run"
+                                     % os.path.relpath(cands[-1], ROOT)}
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "kernel": "k_render_fused", "kernel_us": round(kernel_us, 2), "frames_per_launch": F,
+        kernel_names = {0: ROOFLINE_KERNEL, 1: "k_render_lds<12, 2, false> (the scene's tuning chose it; the issue model was fitted on k_render_fused)",
+                        2: "k_render_paths"}
+        roofline = {"bound": "valu_issue", "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "G SIMD-cycles/s",
+                    "frac": round(frac, 4), "traffic": traffic,
+                    "kernel": kernel_names.get(render_kernel, "?"), "kernel_us": round(kernel_us, 2), "frames_per_launch": Fl,
+                    "model": "node_trips*%.1f + leaf_trips*%.1f + shade_passes*%.1f + waves*%.1f SIMD cycles (profiles/r02_valu_fit.txt, "
+                             "profiles/r02_ubench_valu.txt); %d SIMDs x %.1f GHz" % (
+                                 VALU_CYCLES_PER_TRIP["node"], VALU_CYCLES_PER_TRIP["leaf"], VALU_CYCLES_PER_TRIP["pass"],
+                                 VALU_CYCLES_PER_TRIP["wave"], N_SIMD, CLOCK_GHZ),
+                    "wave_trips_per_launch": {"node": int(sst.node_trips / kn), "leaf": int(sst.leaf_trips / kn),
+                                              "shade_passes": int(sst.shade_passes / kn), "waves": int(sst.waves / kn)},
+                    "lane_utilisation": {"node": round(sst.node_visits / (64.0 * sst.node_trips), 3),
+                                         "leaf": round(sst.tri_tests / (64.0 * sst.leaf_trips), 3),
+                                         "shade": round(sst.rays / (64.0 * sst.shade_passes), 3)},
+                    # the other candidate roofs, as fractions of their peaks (rocprofv3 PMC passes of this kernel at this shape,
+                    # profiles/r02_pmc_fused_monkey_d64.txt; static -- a counter pass cannot run inside the bench):
+                    "roofs": {"valu_issue": round(frac, 4), "l1_texture_addresser_busy": 0.83, "l1_data_return_busy": 0.97,
+                              "hbm_counter_bytes": 0.089, "lds_busy": 0.06,
+                              "source": "valu_issue live (exact trip counters x fitted per-trip cost); the others from profiles/r02_pmc_fused_monkey_d64.txt"},
                     "depth1_kernel_us": round(k1ms / k1n * 1e3, 2) if k1n else None,
                     "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                    "algorithmic_GBps_not_a_roof": round(bytes_per_launch / (kernel_us * 1e-6) / 1e9, 1),
                     "bytes_per_ray": round(algorithmic_bytes(sst) / sst.rays, 1),
                     "survey_formula_bytes_per_ray": round(survey_formula_bytes(sst) / sst.rays, 1),
                     "node_visits_per_ray": round(sst.node_visits / sst.rays, 2),
@@ -247,6 +350,8 @@ def main():
             r.load_scene(mesh.verts, mesh.indices, env)
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(mesh, env)
+        if world == 1 and not args.no_configs:
+            configs = config_records(r, rr, asset, env)
 
     if rank == 0:
         if overflow:
@@ -267,11 +372,14 @@ def main():
                                    "orbit angle 0.01*(k+1), seeded procedural 2048x1024 RGB32F env map",
                        "rays_per_frame": round(total_rays / K, 1),
                        "parallelism": "tiles32x32-roundrobin-x%d%s" % (world, "-rotating-root" if args.rotate_root and world > 1 else ""),
-                       "frames_per_dispatch": F if world == 1 else F * max(1, min(world // 2, 4))},
+                       "frames_per_dispatch": min(K, F if world == 1 else F * max(1, min(world // 2, 4))),
+                       "launch_shape": "DispatchRays(W, H, Depth = frames_per_dispatch): every frame complete in its own buffer; the "
+                                       "reference's own shape, Depth 1, is roofline.depth1_kernel_us"},
             "device_region_ms_per_step": round(region_ms / K, 5) if region_ms is not None else None,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "monkey_16k": subdiv,
+            "configs": configs,
         }
         print(json.dumps(out))
     r.close()

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RRDXR_ABI_VERSION 1
+#define RRDXR_ABI_VERSION 2
 
 typedef enum rr_status {
     RR_OK = 0,
@@ -97,7 +97,16 @@ typedef struct rr_stats {
     uint32_t stats_valid;         /* 1 if the last dispatch ran with RR_DISPATCH_COLLECT_STATS */
     uint32_t traversal_overflow;  /* sticky device error flag of the last dispatch (0 unless a kernel raised it) */
     uint32_t bvh_depth;           /* deepest BLAS / TLAS leaf */
-    uint32_t reserved;
+    uint32_t render_kernel;       /* which kernel rendered the last dispatch: 0 k_render_fused (one lane per pixel, nodes through
+                                     the L1), 1 k_render_lds (the same with persistent workgroups and the nodes in LDS),
+                                     2 k_render_paths (four lanes per pixel); all three produce the same bits */
+    /* wave-level loop trips of the RR_DISPATCH_COLLECT_STATS kernels: a 64-lane wave issues one internal-node step, one
+     * triangle test or one shading pass per trip however many of its lanes take part, so these are what vector-issue
+     * time is made of; node_visits / (64 * node_trips) is the lane utilisation of the internal-node phase, and so on */
+    uint64_t node_trips;
+    uint64_t leaf_trips;
+    uint64_t shade_passes;
+    uint64_t waves;               /* waves that rendered (one 8x8 pixel block each in the block-per-wave kernels) */
 } rr_stats;
 
 typedef struct rr_ray {

@@ -56,7 +56,8 @@ class Stats(C.Structure):
                 ("misses", C.c_uint64), ("terminal_hits", C.c_uint64), ("tir", C.c_uint64),
                 ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("pixels", C.c_uint64),
                 ("stats_valid", C.c_uint32), ("traversal_overflow", C.c_uint32), ("bvh_depth", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("render_kernel", C.c_uint32), ("node_trips", C.c_uint64), ("leaf_trips", C.c_uint64),
+                ("shade_passes", C.c_uint64), ("waves", C.c_uint64)]
 
 
 # every symbol include/rrdxr.h declares: name -> (restype, argtypes)
@@ -140,7 +141,7 @@ def lib():
             fn = getattr(L, name)      # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.rr_abi_version() != 1:
+        if L.rr_abi_version() != 2:
             raise RuntimeError("librrdxr.so ABI version mismatch")
         _lib = L
     return _lib

@@ -141,6 +141,15 @@ struct rr_context {
     CounterBlock* d_cnt = nullptr;
     uint32_t* d_park[MAX_LANES + 1] = {};   // k_render_lds: parked reflected rays, one slab per stream slot like the tickets
     size_t    park_bytes[MAX_LANES + 1] = {};
+    // k_render_lds or k_render_fused for launches of many slices?  Neither wins everywhere (sphere.obj / shell.obj 1080p: the LDS
+    // kernel by 6 % all round the orbit; monkey.obj: the L1-fed one by 2 %), and which does depends on how busy the texture
+    // path is, not on anything the host can see.  So the first two eligible launches of a scene are timed with HIP events, one
+    // on each kernel (adjacent slices of the same orbit), and the faster per slice renders the rest.  Frames are bit-identical.
+    int        tune_state = 0;       // 0 nothing tried, 1 fused trial issued, 2 LDS trial issued, 3 decided
+    hipEvent_t tune_ev[4] = {};
+    uint32_t   tune_depth[2] = { 0, 0 };
+    bool       tune_lds = false;
+    uint32_t   last_kernel = 0;      // render kernel of the last dispatch: 0 k_render_fused, 1 k_render_lds, 2 k_render_paths, 3 experimental
     uint32_t* d_tickets = nullptr;   // k_render_lds ticket words: one block per stream a launch can be on (lanes, then the context's stream)
 
     // diagnostics switches, read once at rr_create (never needed for correct results)
@@ -374,6 +383,7 @@ int rr_destroy(rr_context* ctx)
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->tune_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return RR_OK;
@@ -630,6 +640,7 @@ int rr_build_tlas(rr_context* ctx, const rr_instance_desc* instances, uint32_t n
     ctx->single_identity = n == 1 && host[0].identity && (d0.hitgroup_flags >> 24) == 0 && ((d0.instance_id_mask >> 24) & 0xffu) != 0;
     if (scene_stack_need(ctx) > 64) return fail(ctx, RR_ERR_UNSUPPORTED, "rr_build_tlas: TLAS+BLAS deeper than the 64-entry stack");
     ctx->tlas_built = true;
+    ctx->tune_state = 0;
     return RR_OK;
 }
 
@@ -753,6 +764,8 @@ void mesh_screen_rect(const float box[6], const rr_scene_constants* cams, uint32
     r[0] = lo8(x0, W8); r[1] = lo8(y0, H8); r[2] = hi8(x1, W8); r[3] = hi8(y1, H8);
 }
 
+inline bool timed_request(const rr_dispatch_params& p) { return (p.flags & RR_DISPATCH_TIME_KERNEL) != 0; }
+
 // out_slot: which of the frames_in_flight output regions of the internal frame buffer this dispatch writes;
 // h_cams: host copy of the depth slices' constants (may be null: no ordering hint)
 int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t depth, const CamDev* d_cams,
@@ -869,13 +882,32 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     const uint32_t node_bytes = m0 ? (m0->n_tris > 1 ? m0->n_tris - 1 : 1) * (uint32_t)sizeof(QNode) : 0;
     // share of the frame in which the scene can be seen at all in these slices
     const double rect_share = (double)(a.hx1 - a.hx0) * (double)(a.hy1 - a.hy0) / ((double)width * (double)height);
-    // Worth it for launches of many slices in which the mesh fills a good part of the frame (sphere.obj / shell.obj at 1080p,
-    // Depth 64: 6 % faster than the L1-fed kernel, whose texture addresser is then 83-90 % busy; monkey.obj, whose screen
-    // rectangle is a fifth of the frame: 3 % slower -- the persistent kernel executes 6 % more vector instructions and both
-    // are bound by vector issue).  A launch of few slices ends on its most expensive blocks and pays for 768 waves sharing a
-    // ticket word: the hardware's own workgroup dispatch does better there.  RR_DEBUG_KERNEL=lds forces it wherever it fits.
-    const bool lds_kernel = m0 && (ctx->dbg_kernel == 4 || (ctx->dbg_kernel == 0 && depth >= 32 && rect_share >= 0.25)) && ctx->dbg_stack == 0 &&
-                            m0->n_tris < 32768u && lds_kernel_shape(node_bytes, need + 1, nullptr, ctx->dbg_shape) >= 0;
+    // k_render_lds for launches of many slices, where the scene's tuning says so (rr_context::tune_state).  A launch of few
+    // slices ends on its most expensive blocks and pays for 768 waves sharing a ticket word: the hardware's own workgroup
+    // dispatch does better there.  RR_DEBUG_KERNEL=lds forces it wherever it fits, =fused never uses it.
+    const bool lds_fits = m0 && ctx->dbg_stack == 0 && m0->n_tris < 32768u && lds_kernel_shape(node_bytes, need + 1, nullptr, ctx->dbg_shape) >= 0;
+    bool lds_kernel = lds_fits && ctx->dbg_kernel == 4;
+    int tune_slot = -1;             // this launch is one of the two trials: bracket it with events
+    bool on_lane = false;           // lanes overlap their launches: no place for a timing trial
+    for (uint32_t l = 0; l < rr_context::MAX_LANES; ++l) if (ctx->lane_stream[l] && ctx->stream == ctx->lane_stream[l]) on_lane = true;
+    if (lds_fits && ctx->dbg_kernel == 0 && depth >= 32) {
+        const bool may_try = !stats && !timed_request(p) && !on_lane;
+        if (ctx->tune_state == 2 && hipEventQuery(ctx->tune_ev[3]) == hipSuccess) {       // both trials done: decide
+            float ms_f = 0.0f, ms_l = 0.0f;
+            if (hipEventElapsedTime(&ms_f, ctx->tune_ev[0], ctx->tune_ev[1]) == hipSuccess &&
+                hipEventElapsedTime(&ms_l, ctx->tune_ev[2], ctx->tune_ev[3]) == hipSuccess && ms_f > 0.0f && ms_l > 0.0f)
+                ctx->tune_lds = ms_l / (float)ctx->tune_depth[1] < 0.97f * (ms_f / (float)ctx->tune_depth[0]);     // a tie stays with k_render_fused
+            ctx->tune_state = 3;
+        }
+        if (ctx->tune_state == 0 && may_try) { tune_slot = 0; }
+        else if (ctx->tune_state == 1 && may_try) { tune_slot = 1; lds_kernel = true; }
+        else if (ctx->tune_state == 3) lds_kernel = ctx->tune_lds;
+        if (tune_slot >= 0) {
+            for (int k = 0; k < 4; ++k) if (!ctx->tune_ev[k]) RR_HIP(hipEventCreate(&ctx->tune_ev[k]));
+            ctx->tune_depth[tune_slot] = depth;
+            RR_HIP(hipEventRecord(ctx->tune_ev[tune_slot * 2], ctx->stream));
+        }
+    }
     // Launches of one or two slices whose scene is small on screen last as long as their most expensive wave: there the
     // path-parallel kernel (four lanes per pixel inside the scene's screen rectangle: a fifth of the longest chain of
     // dependent rays, four waves per block) wins -- monkey.obj 1080p Depth 1: 268 us against 471, ott.obj 626 against 1 419.
@@ -927,6 +959,10 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         if (depth <= 2) stack16 = false;
         RR_HIP(launch_render_fused(sc, a, stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream, stack16, ctx->dbg_kernel == 2));
     }
+    if (tune_slot >= 0) {
+        RR_HIP(hipEventRecord(ctx->tune_ev[tune_slot * 2 + 1], ctx->stream));
+        ctx->tune_state = tune_slot + 1;
+    }
     if (timed) {
         RR_HIP(hipEventRecord(ctx->kev[(size_t)ctx->kev_used * 2 + 1], ctx->stream));
         ++ctx->kev_used;
@@ -938,6 +974,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         (void)hipFree(d_diag);
         if (FILE* f = fopen(diag_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
+    ctx->last_kernel = wavefront ? 3u : paths_kernel ? 2u : lds_kernel ? 1u : 0u;
     ctx->W = width; ctx->H = height; ctx->frame_world = ctx->tile_world; ctx->frame_depth = depth;
     ctx->have_f32 = want_f32; ctx->have_frame = ext_tiles == nullptr; ctx->have_assembled = false;
     if (!ext_tiles) ctx->frame_base = out_base;
@@ -1298,9 +1335,12 @@ int rr_get_stats(rr_context* ctx, rr_stats* out)
     if (ctx->last_stats) {
         out->hits = h->counters[C_HITS]; out->misses = h->counters[C_MISSES]; out->terminal_hits = h->counters[C_TERMINAL];
         out->tir = h->counters[C_TIR]; out->node_visits = h->counters[C_NODES]; out->tri_tests = h->counters[C_TRIS];
+        out->node_trips = h->counters[C_NODE_TRIPS]; out->leaf_trips = h->counters[C_LEAF_TRIPS];
+        out->shade_passes = h->counters[C_PASSES]; out->waves = h->counters[C_WAVES];
     }
     out->traversal_overflow = h->error;
     out->bvh_depth = scene_stack_need(ctx);
+    out->render_kernel = ctx->last_kernel;
     free(h);
     return RR_OK;
 }

@@ -101,7 +101,14 @@ struct HitRec {
     bool hit;
 };
 
-struct TravCounters { uint32_t nodes, tris; };
+// nodes, tris: per-lane visits.  node_trips, leaf_trips: wave-level loop trips (STATS builds only; counted by the lowest
+// active lane of each trip): the vector unit issues an internal-node step or a triangle test once per trip whatever the
+// number of lanes that take part, so these -- not the lane counts -- are what its time is spent on.
+struct TravCounters { uint32_t nodes, tris, node_trips = 0, leaf_trips = 0; };
+__device__ __forceinline__ bool first_active_lane()
+{
+    return (int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(1)) - 1;
+}
 
 constexpr uint32_t CULL_BACK = 0x10u, CULL_FRONT = 0x20u;
 
@@ -344,7 +351,7 @@ __device__ __forceinline__ void trace_blas(const BlasDev& bl, f3 O, f3 D, float 
             if (leaf_phase_due(n_in)) break;
             diag_trip(dg);
             const NodeQ q = ns.load(nodes, node);
-            if (STATS) cnt.nodes++;
+            if (STATS) { cnt.nodes++; if (first_active_lane()) cnt.node_trips++; }
             node = node_step(br, q, tmin, best.t, top, stk);
 #ifdef RR_EXP_EXTRA_VALU      // experiment: what do N more VALU instructions per visit cost?
             { float dv = br.inv.x;
@@ -356,7 +363,7 @@ __device__ __forceinline__ void trace_blas(const BlasDev& bl, f3 O, f3 D, float 
         // leaf phase: every lane that holds a leaf tests its triangle and pops
         if (node < 0 && node != TRAV_DONE) {
             diag_trip(dg, 1);
-            if (STATS) cnt.tris++;
+            if (STATS) { cnt.tris++; if (first_active_lane()) cnt.leaf_trips++; }
             tri_test(bl.tris, (uint32_t)~node, O, D, tmin, cull, inst, best);
             if (top > stk) { top -= STACK_STRIDE; node = StackCodec<E>::dec(*top); } else node = TRAV_DONE;
         }
@@ -405,7 +412,7 @@ __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, floa
     for (;;) {
         while (node >= 0) {                     // (the early hand-over of trace_blas costs 13-16 % here: C4, C5 measured)
             const NodeQ q = load_node(nodes, node);
-            if (STATS) cnt.nodes++;
+            if (STATS) { cnt.nodes++; if (first_active_lane()) cnt.node_trips++; }
             node = node_step(br, q, tmin, best.t, top, floor);
         }
         if (node == TRAV_DONE) {
@@ -416,6 +423,7 @@ __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, floa
             break;
         }
         const uint32_t L = (uint32_t)~node;
+        if (STATS && first_active_lane()) cnt.leaf_trips++;          // a trip of the two-level loop's leaf part: triangle tests and instance entries
         if (L < sc.n_pool_tris) {
             if (STATS) cnt.tris++;
             tri_test(sc.pool_tris, L, Oc, Dc, tmin, cull, cur, best);

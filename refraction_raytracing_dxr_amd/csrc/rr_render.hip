@@ -57,6 +57,8 @@ __device__ __forceinline__ void block_to_tile(uint32_t b, uint32_t& tile_local, 
 // per-lane tallies of one wave's work (reduced and added to the dispatch counters once, when the wave ends)
 struct LaneStats {
     uint32_t rays = 0, hits = 0, miss = 0, term = 0, tir = 0, pixels = 0;
+    uint32_t passes = 0;            // wave-level shading passes (ray rounds), STATS builds
+    uint32_t blocks = 0;            // 8x8 pixel blocks this wave rendered (wave-uniform)
     TravCounters cnt = { 0, 0 };
 };
 
@@ -126,6 +128,7 @@ __device__ __forceinline__ f3 render_pixel(const SceneDev& sc, const DispatchDev
         else h.hit = false;
         may_hit = true;
         ++st.rays;
+        if (STATS && first_active_lane()) ++st.passes;
         if (DIAG) diag_trip(dg, 2);
         bool have_next = false;
         if (!h.hit) {                                             // Miss
@@ -210,6 +213,10 @@ __device__ __forceinline__ void flush_stats(const DispatchDev& a, const LaneStat
         v = wave_reduce_add(st.cnt.nodes); if (lane == 0 && v) atomicAdd(&a.counters[C_NODES], (unsigned long long)v);
         v = wave_reduce_add(st.cnt.tris);  if (lane == 0 && v) atomicAdd(&a.counters[C_TRIS], (unsigned long long)v);
         v = wave_reduce_add(st.pixels); if (lane == 0 && v) atomicAdd(&a.counters[C_PRIMARY], (unsigned long long)v);
+        v = wave_reduce_add(st.cnt.node_trips); if (lane == 0 && v) atomicAdd(&a.counters[C_NODE_TRIPS], (unsigned long long)v);
+        v = wave_reduce_add(st.cnt.leaf_trips); if (lane == 0 && v) atomicAdd(&a.counters[C_LEAF_TRIPS], (unsigned long long)v);
+        v = wave_reduce_add(st.passes); if (lane == 0 && v) atomicAdd(&a.counters[C_PASSES], (unsigned long long)v);
+        if (lane == 0 && st.blocks) atomicAdd(&a.counters[C_WAVES], (unsigned long long)st.blocks);
     }
 }
 
@@ -253,6 +260,7 @@ __global__ __launch_bounds__(256, TLAS ? RR_TLAS_WAVES_PER_SIMD(STACK) : sizeof(
     float4* const out_f32 = a.out_f32 ? a.out_f32 + (size_t)bp.frame * a.frame_stride : nullptr;
 
     LaneStats st;
+    st.blocks = bp.tile_ok ? 1u : 0u;
     if (valid) {
         st.pixels = 1;
         RegPark<PEND> park;
@@ -312,6 +320,7 @@ __device__ __forceinline__ PathLeaf render_path(const SceneDev& sc, const Dispat
         TravCounters cnt; cnt.nodes = 0; cnt.tris = 0;
         trace_scene<STATS, TLAS, E, GlobalNodes>(sc, O, D, tmin, tmax, outside ? CULL_BACK : CULL_FRONT, h, stk, cnt);
         if (owner) { ++st.rays; if (STATS) { st.cnt.nodes += cnt.nodes; st.cnt.tris += cnt.tris; } }
+        if (STATS) { st.cnt.node_trips += cnt.node_trips; st.cnt.leaf_trips += cnt.leaf_trips; if (first_active_lane()) ++st.passes; }
         if (!h.hit) {                                             // Miss
             if (owner) { if (STATS) ++st.miss; leaf.w = w; leaf.e = env_lookup(sc, D); }
             break;
@@ -363,6 +372,7 @@ __global__ __launch_bounds__(256, 8) void k_render_paths(SceneDev sc, DispatchDe
         const uint32_t x = x0 + (pix & 3u), y = y0 + (pix >> 2);
         const bool valid = x < a.W && y < a.H;
         PathLeaf lf; lf.w = 0.0f; lf.e = mk3(0.0f, 0.0f, 0.0f);
+        st.blocks = 1u;                 // (a quarter of an 8x8 block: the per-wave cost of the issue model does not apply to this kernel)
         if (valid) {
             if (path == 0u) st.pixels = 1;
             lf = render_path<STATS, TLAS, uint32_t>(sc, a, a.cams[frame], x, y, path, stk, st);
@@ -509,6 +519,7 @@ __global__ __launch_bounds__(NW * 64, NW * WGS / 4) void k_render_lds(SceneDev s
             ++phase; qi = home; stealing = false;
         }
         if (!have) break;
+        st.blocks += 1u;
         const unsigned long long dr0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
         const uint32_t dI0 = DIAG ? diag_tr[wave] : 0u, dL0 = DIAG ? diag_tr[16 + wave] : 0u, dS0 = DIAG ? diag_tr[32 + wave] : 0u;
         const uint32_t x = bp.x0 + lx, y = bp.y0 + ly;
