@@ -12,14 +12,20 @@ LIB = os.path.join(PKG, "librrdxr.so")
 DEMO = os.path.join(PKG, "rrdemo")
 
 DEVICE_SOURCES = ["rr_bvh_build.hip", "rr_render.hip"]
+# RR_EXPERIMENTAL=1: also build the render-kernel experiments (rr_render_exp.hip: lane-asynchronous, queue-per-bounce and
+# pixel-refill renderers, selected at run time with RR_DEBUG_KERNEL); the product library does not contain them
+EXPERIMENTAL = os.environ.get("RR_EXPERIMENTAL") == "1"
+if EXPERIMENTAL:
+    DEVICE_SOURCES.append("rr_render_exp.hip")
 HOST_SOURCES = ["rr_capi.cpp", "host/rr_host_camera.cpp", "host/rr_host_mesh.cpp", "host/rr_host_image.cpp",
                 "host/Mesh.cpp", "host/RefractionDemo.cpp"]
-HEADERS = ["rr_types.h", "rr_device.h", "rr_launch.h", "host/Mesh.hpp", "host/RefractionDemo.hpp",
+HEADERS = ["rr_types.h", "rr_device.h", "rr_launch.h", "rr_render_common.h", "host/Mesh.hpp", "host/RefractionDemo.hpp",
            "../../include/rrdxr.h"]
 
 # -ffp-contract=off: the arithmetic contract -- FMAs only where fmaf is written
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
-DEVICE_FLAGS = ["--offload-arch=gfx950", "-fno-gpu-rdc"] + os.environ.get("RR_EXTRA_DEFINES", "").split()
+DEVICE_FLAGS = (["--offload-arch=gfx950", "-fno-gpu-rdc"] + (["-DRR_EXPERIMENTAL"] if EXPERIMENTAL else []) +
+                os.environ.get("RR_EXTRA_DEFINES", "").split())
 
 
 def _hipcc():
@@ -43,6 +49,10 @@ def build(force=False, verbose=False):
     deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     objdir = os.path.join(PKG, "build")
     os.makedirs(objdir, exist_ok=True)
+    stamp = os.path.join(objdir, "flags.txt")          # the flags the objects were built with: a change rebuilds everything
+    flags = " ".join(COMMON + DEVICE_FLAGS + DEVICE_SOURCES)
+    if not os.path.exists(stamp) or open(stamp).read() != flags:
+        force = True
     objs = []
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s) + ".o")
@@ -57,6 +67,8 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
+    with open(stamp, "w") as f:
+        f.write(flags)
     demo_src = os.path.join(CSRC, "tools", "rrdemo.cpp")
     if force or _stale(DEMO, [demo_src, LIB]):
         cmd = [hipcc, demo_src, "-o", DEMO, "-O2", "-std=c++17", "-L" + PKG, "-lrrdxr", "-Wl,-rpath,$ORIGIN"]

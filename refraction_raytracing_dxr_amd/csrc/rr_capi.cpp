@@ -353,7 +353,7 @@ int rr_create(int device_ordinal, rr_context** out)
     (void)hipMemsetAsync(ctx->d_cnt, 0, sizeof(CounterBlock), ctx->stream);
     (void)hipMemsetAsync(ctx->d_tickets, 0, (rr_context::MAX_LANES + 1) * LDS_TICKET_WORDS * sizeof(uint32_t), ctx->stream);   // the kernel leaves them zero
     if (const char* e = getenv("RR_DEBUG_KERNEL"))
-        ctx->dbg_kernel = !strcmp(e, "fused") ? 1 : !strcmp(e, "async") ? 2 : !strcmp(e, "wavefront") ? 3 : !strcmp(e, "lds") ? 4 : !strcmp(e, "paths") ? 5 : 0;
+        ctx->dbg_kernel = !strcmp(e, "fused") ? 1 : !strcmp(e, "async") ? 2 : !strcmp(e, "wavefront") ? 3 : !strcmp(e, "lds") ? 4 : !strcmp(e, "paths") ? 5 : !strcmp(e, "refill") ? 6 : 0;
     if (const char* e = getenv("RR_DEBUG_STACK")) ctx->dbg_stack = atoi(e);
     if (const char* e = getenv("RR_DEBUG_TICKET")) ctx->dbg_ticket_blocks = atoi(e);
     if (const char* e = getenv("RR_DEBUG_SHAPE")) ctx->dbg_shape = atoi(e);
@@ -859,7 +859,11 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         RR_HIP(hipEventRecord(ctx->kev[(size_t)ctx->kev_used * 2], ctx->stream));
     }
     int stack_sel = need <= 19 ? 19 : need <= 22 ? 22 : need <= 26 ? 26 : need <= 31 ? 31 : need <= 39 ? 39 : 64;     // rr_render.hip: sizes that fill the LDS with 6 / 5 / 4 / 2 workgroups
+#ifdef RR_EXPERIMENTAL
     const bool wavefront = ctx->dbg_kernel == 3 && ctx->single_identity && !compact && !want_f32 && !stats && p.max_reflect <= 2 && p.max_refract < 62;
+#else
+    const bool wavefront = false;
+#endif
     if (wavefront) {        // experiment: queue-per-bounce kernels; buffers sized for this dispatch
         const size_t px = (size_t)width * height * depth;
         if (px > ctx->wf_pixels) {
@@ -916,8 +920,28 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     const bool have_rect = a.hx1 > a.hx0 && a.hy1 > a.hy0;
     const bool paths_kernel = (ctx->dbg_kernel == 5 || (ctx->dbg_kernel == 0 && depth <= 2 && rect_share < 0.25)) && !compact && ctx->tile_world == 1 &&
                               p.max_reflect <= 2 && need <= 39 && !a.diag && ctx->dbg_stack == 0 && have_rect;
+    uint32_t pool_nodes = 0;
+    if (!ctx->single_identity) {
+        pool_nodes = ctx->n_insts > 1 ? ctx->n_insts - 1 : 1;
+        std::vector<char> seen(ctx->meshes.size(), 0);
+        for (uint32_t i = 0; i < ctx->n_insts; ++i) {
+            const size_t mi = (size_t)ctx->inst_host[i].blas;
+            if (!seen[mi]) { seen[mi] = 1; pool_nodes += ctx->meshes[mi].n_tris > 1 ? ctx->meshes[mi].n_tris - 1 : 1; }
+        }
+    }
+    const bool refill_stack16 = ctx->single_identity ? (m0 && m0->n_tris < 32768u && need > 19)
+                                                     : (pool_nodes < 32768u && ctx->n_pool_tris + ctx->n_insts < 32768u);
+    // (experiment, RR_DEBUG_KERNEL=refill: on the 1 024-monkey grid it raises the share of live lanes per shading pass from
+    // 54 % to 80 % and the frame time from 8.9 to 10.8 ms -- a pass lasts as long as its longest ray either way, and with
+    // every lane alive that one is longer)
+    const bool refill_kernel = ctx->dbg_kernel == 6 && p.max_reflect <= 2 && need <= 39 && !a.diag && ctx->dbg_stack == 0 && !paths_kernel;
+#ifdef RR_EXPERIMENTAL
     if (wavefront) RR_HIP(launch_render_wavefront(sc, a, ctx->wf, stack_sel, ctx->stream));
-    else if (paths_kernel) RR_HIP(launch_render_paths(sc, a, (int)need, stats, ctx->stream));
+    else if (refill_kernel) RR_HIP(launch_render_refill(sc, a, (int)need, stats, ctx->stream, refill_stack16));
+    else if (ctx->dbg_kernel == 2 && ctx->single_identity) RR_HIP(launch_render_async(sc, a, stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream));
+    else
+#endif
+    if (paths_kernel) RR_HIP(launch_render_paths(sc, a, (int)need, stats, ctx->stream));
     else if (lds_kernel) {
         LdsDispatch q;
         memset(&q, 0, sizeof q);
@@ -944,7 +968,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         // (monkey.obj Depth 64: 90 us per frame, 104 with 32 queues entered by wave number)
         q.n_queues = (ctx->dbg_ticket_blocks & 64) ? 64u : (ctx->dbg_ticket_blocks & 128) ? LDS_QUEUES : 8u;   // launch_render_lds caps it at the grid size
         q.home_xcc = (ctx->dbg_ticket_blocks & 16) ? 0u : 1u;
-        q.dbg_regpark = (ctx->dbg_ticket_blocks & 32) ? 1u : 0u;
+
         q.rx0 = rect[0]; q.ry0 = rect[1]; q.rx1 = rect[2]; q.ry1 = rect[3];
         q.node_bytes = node_bytes;
         q.stack_entries = need + 1;                     // the tree's depth bounds the stack; one entry to spare
@@ -957,7 +981,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         // spills of the 6..8-wave builds (monkey Depth 1: 446 us with the 5-wave build, 475 with the 8-wave one)
         if (depth <= 2 && ctx->single_identity && stack_sel < 31 && ctx->dbg_stack == 0) { stack_sel = 31; stack16 = false; }
         if (depth <= 2) stack16 = false;
-        RR_HIP(launch_render_fused(sc, a, stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream, stack16, ctx->dbg_kernel == 2));
+        RR_HIP(launch_render_fused(sc, a, stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream, stack16));
     }
     if (tune_slot >= 0) {
         RR_HIP(hipEventRecord(ctx->tune_ev[tune_slot * 2 + 1], ctx->stream));
@@ -974,7 +998,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         (void)hipFree(d_diag);
         if (FILE* f = fopen(diag_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
-    ctx->last_kernel = wavefront ? 3u : paths_kernel ? 2u : lds_kernel ? 1u : 0u;
+    ctx->last_kernel = wavefront ? 3u : paths_kernel ? 2u : refill_kernel ? 4u : lds_kernel ? 1u : 0u;
     ctx->W = width; ctx->H = height; ctx->frame_world = ctx->tile_world; ctx->frame_depth = depth;
     ctx->have_f32 = want_f32; ctx->have_frame = ext_tiles == nullptr; ctx->have_assembled = false;
     if (!ext_tiles) ctx->frame_base = out_base;

@@ -400,14 +400,14 @@ __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, floa
         trace_blas<STATS, E, NS>(sc.blas0, O, D, tmin, flags, 0u, best, stk_e, cnt, dg, ns);
         return;
     }
-    uint32_t* stk = reinterpret_cast<uint32_t*>(stk_e);      // the two-level loop always runs on 32-bit entries
+    E* stk = stk_e;                         // (16-bit entries: scenes of fewer than 32 768 pool nodes and triangles + instances)
     const QNode* __restrict__ nodes = sc.pool_nodes;
     constexpr uint32_t NO_INST = 0xffffffffu;
     BoxRay br = box_ray(O, D, sc.scale, sc.grid);
     f3 Oc = O, Dc = D;                      // the ray in the space of the level being walked
     uint32_t cull = flags, cur = NO_INST;
-    uint32_t* top = stk;
-    const uint32_t* floor = stk;            // floor: stack level at which the current instance was entered
+    E* top = stk;
+    const E* floor = stk;                   // floor: stack level at which the current instance was entered
     int node = 0;
     for (;;) {
         while (node >= 0) {                     // (the early hand-over of trace_blas costs 13-16 % here: C4, C5 measured)
@@ -419,7 +419,7 @@ __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, floa
             if (cur == NO_INST) break;
             cur = NO_INST; Oc = O; Dc = D; cull = flags; floor = stk;        // leave the instance
             br = box_ray(O, D, sc.scale, sc.grid);
-            if (top > stk) { top -= STACK_STRIDE; node = (int)*top; continue; }
+            if (top > stk) { top -= STACK_STRIDE; node = StackCodec<E>::dec(*top); continue; }
             break;
         }
         const uint32_t L = (uint32_t)~node;
@@ -427,7 +427,7 @@ __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, floa
         if (L < sc.n_pool_tris) {
             if (STATS) cnt.tris++;
             tri_test(sc.pool_tris, L, Oc, Dc, tmin, cull, cur, best);
-            if (top > floor) { top -= STACK_STRIDE; node = (int)*top; } else node = TRAV_DONE;
+            if (top > floor) { top -= STACK_STRIDE; node = StackCodec<E>::dec(*top); } else node = TRAV_DONE;
         } else {
             const uint32_t ii = L - sc.n_pool_tris;
             const InstDev& in = sc.insts[ii];
@@ -442,7 +442,7 @@ __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, floa
                 if (!in.identity) { Oc = xform_point(in.inv, O); Dc = xform_dir(in.inv, D); }
                 br = box_ray(Oc, Dc, in.scale, in.grid);
                 node = (int)in.root;
-            } else if (top > stk) { top -= STACK_STRIDE; node = (int)*top; } else node = TRAV_DONE;
+            } else if (top > stk) { top -= STACK_STRIDE; node = StackCodec<E>::dec(*top); } else node = TRAV_DONE;
         }
     }
     if (best.hit) {                             // the ray in the space of the instance that was hit, as at its entry

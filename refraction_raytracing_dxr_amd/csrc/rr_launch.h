@@ -12,7 +12,7 @@ static_assert(sizeof(rr_ray_dev) == 48 && sizeof(rr_hit_dev) == 24, "ABI layout"
 
 // ---- rr_render.hip
 hipError_t launch_render_fused(const SceneDev& sc, const DispatchDev& a, int stack, int pend, bool stats, hipStream_t s,
-                               bool stack16 = false, bool async = false);
+                               bool stack16 = false);
 // BLAS nodes in LDS, persistent workgroups (single identity instance whose node array fits: lds_kernel_shape() >= 0)
 // shapes (waves per workgroup x workgroups per CU): 0 = 12x2 (the product shape), 1 = 16x2, 2 = 16x1 (experiments:
 // RR_DEBUG_SHAPE = first shape to consider); -1: the node array does not fit
@@ -34,8 +34,9 @@ hipError_t launch_assemble_frames_rgb8(const uint8_t* gathered, uint32_t* frames
                                        uint32_t world, size_t rank_stride_b, size_t frame_stride_b, size_t out_stride, uint32_t n_frames,
                                        hipStream_t s);
 
-// ---- experimental queue-per-bounce renderer (rr_render.hip, RR_DEBUG_KERNEL=wavefront; single identity instance,
-// max_reflect <= 2): ray queues (48 B records, ping-pong), four (w, texel) slots per pixel, the list of covered pixels
+// ---- experiments (rr_render_exp.hip, only in builds made with RR_EXPERIMENTAL=1; RR_DEBUG_KERNEL selects them) ----------
+// queue-per-bounce renderer (single identity instance, max_reflect <= 2): ray queues (48 B records, ping-pong), four
+// (w, texel) slots per pixel, the list of covered pixels
 struct WfBuffers {
     float4*   q[2];        // cap records of 3 x float4 each
     float4*   slots;       // [pixel index][4]: one slot per leaf of the pixel's ray tree, in depth-first order
@@ -43,7 +44,13 @@ struct WfBuffers {
     uint32_t* counts;      // [0] unused, [g] rays queued for bounce g (1..62), [63] covered pixels
     uint32_t  cap;         // queue capacity in rays
 };
+#ifdef RR_EXPERIMENTAL
 hipError_t launch_render_wavefront(const SceneDev& sc, const DispatchDev& a, const WfBuffers& wf, int stack, hipStream_t s);
+// lane-asynchronous form of k_render_fused (single identity instance)
+hipError_t launch_render_async(const SceneDev& sc, const DispatchDev& a, int stack, int pend, bool stats, hipStream_t s);
+// pixel refill (k_render_refill): a wave's lanes take the next pixel of its 256-pixel column as theirs finish
+hipError_t launch_render_refill(const SceneDev& sc, const DispatchDev& a, int stack, bool stats, hipStream_t s, bool stack16);
+#endif
 
 // ---- rr_bvh_build.hip
 // Scratch + outputs of one LBVH build over n primitives (triangles of a mesh, or instances).

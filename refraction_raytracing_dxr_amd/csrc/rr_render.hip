@@ -12,233 +12,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <cstring>
-#include <type_traits>
-#include "rr_device.h"
-#include "rr_launch.h"
-
-// Stack sizes and waves per SIMD go together: a workgroup's four stacks take STACK KiB of LDS and a CU lets about
-// 156 KiB be allocated (tools/ubench_occupancy.hip: six workgroups are resident up to 26 624 B each, five up to
-// 31 744 B, four up to 40 960 B -- 32 768 B already drops to four).  So the instantiations are 26 entries (6 waves
-// per SIMD, 80 VGPRs), 31 (5 waves, 96 VGPRs), 39 (4 waves) and 64 (2 waves).  Measured at Depth 64, us/frame on
-// monkey / sphere: 4 waves 123 / 214, 5 waves 108 / 189, 6 waves (15 words spilled) 104 / 183.
-#ifndef RR_FUSED_WAVES_PER_SIMD
-#define RR_FUSED_WAVES_PER_SIMD(STACK) ((STACK) <= 19 ? 8 : (STACK) <= 22 ? 7 : (STACK) <= 26 ? 6 : (STACK) <= 31 ? 5 : (STACK) <= 39 ? 4 : 2)
-#endif
-#ifndef RR_TLAS_WAVES_PER_SIMD
-#define RR_TLAS_WAVES_PER_SIMD(STACK) ((STACK) <= 31 ? 5 : (STACK) <= 39 ? 4 : 2)      // C5: 9.70 -> 9.35 ms with 5 (96 VGPRs, spills)
-#endif
+#include "rr_render_common.h"
 
 namespace rr {
-
-struct PendRay {
-    float ox, oy, oz, dx, dy, dz, w;
-    uint32_t meta;          // count | outside << 16
-};
-
-__device__ __forceinline__ uint32_t compact1by1(uint32_t v)
-{
-    v &= 0x55555555u;
-    v = (v ^ (v >> 1)) & 0x33333333u;
-    v = (v ^ (v >> 2)) & 0x0f0f0f0fu;
-    return v;
-}
-
-// Blocks b and b+8 share an XCD (round-robin dispatch).  The four 32x8 strips of a tile go to one XCD
-// (they share BVH subtrees and env-map lines in that XCD's L2) while consecutive tiles go to
-// consecutive XCDs: coverage is centre-heavy (the mesh fills ~7 % of the frame but owns a third of
-// the rays), so giving an XCD a contiguous image region would leave most of the chip idle.
-__device__ __forceinline__ void block_to_tile(uint32_t b, uint32_t& tile_local, uint32_t& strip)
-{
-    const uint32_t xcd = b & 7u, slot = b >> 3;
-    tile_local = (slot >> 2) * 8u + xcd;
-    strip = slot & 3u;
-}
-
-// per-lane tallies of one wave's work (reduced and added to the dispatch counters once, when the wave ends)
-struct LaneStats {
-    uint32_t rays = 0, hits = 0, miss = 0, term = 0, tir = 0, pixels = 0;
-    uint32_t passes = 0;            // wave-level shading passes (ray rounds), STATS builds
-    uint32_t blocks = 0;            // 8x8 pixel blocks this wave rendered (wave-uniform)
-    TravCounters cnt = { 0, 0 };
-};
-
-// One pixel: RayGen (RayTracing.hlsl:42-64), then the pixel's whole ray tree depth-first -- ClosestHit (hlsl:79-125)
-// spawns the refracted child (followed at once) and the reflected child (parked in registers), Miss (hlsl:127-137)
-// adds weight * texel.  Returns the pixel's colour, the sum of its leaves in the recursion's order.
-// Where a pixel's parked reflected rays wait.  RegPark: in registers (PEND slots of 8 words: they stay live through every
-// traversal and are most of what the 64-register builds spill).  MemPark: in a per-wave slab of device memory, field by
-// field, 64 lanes to a 256-byte row -- written once per spawned reflection and read once when it is resumed (0.3 times per
-// ray), so the traversal loops carry 8 * PEND registers less.
-template <int PEND>
-struct RegPark {
-    PendRay pend[PEND];
-    __device__ __forceinline__ void put(int k, const PendRay& p)
-    {
-#pragma unroll
-        for (int i = 0; i < PEND; ++i) if (i == k) pend[i] = p;
-    }
-    __device__ __forceinline__ PendRay get(int k) const
-    {
-        PendRay p = pend[0];
-#pragma unroll
-        for (int i = 1; i < PEND; ++i) if (i == k) p = pend[i];
-        return p;
-    }
-};
-struct MemPark {
-    uint32_t* base;         // this lane's column of the wave's slab: word f of slot k at base[(k * 8 + f) * 64]
-    __device__ __forceinline__ void put(int k, const PendRay& p)
-    {
-        uint32_t* q = base + (size_t)k * (8 * 64);
-        q[0 * 64] = __float_as_uint(p.ox); q[1 * 64] = __float_as_uint(p.oy); q[2 * 64] = __float_as_uint(p.oz);
-        q[3 * 64] = __float_as_uint(p.dx); q[4 * 64] = __float_as_uint(p.dy); q[5 * 64] = __float_as_uint(p.dz);
-        q[6 * 64] = __float_as_uint(p.w);  q[7 * 64] = p.meta;
-    }
-    __device__ __forceinline__ PendRay get(int k) const
-    {
-        const uint32_t* q = base + (size_t)k * (8 * 64);
-        PendRay p;
-        p.ox = __uint_as_float(q[0 * 64]); p.oy = __uint_as_float(q[1 * 64]); p.oz = __uint_as_float(q[2 * 64]);
-        p.dx = __uint_as_float(q[3 * 64]); p.dy = __uint_as_float(q[4 * 64]); p.dz = __uint_as_float(q[5 * 64]);
-        p.w = __uint_as_float(q[6 * 64]);  p.meta = q[7 * 64];
-        return p;
-    }
-};
-
-// may_hit (wave-uniform): false for a block outside the screen rectangle of the scene (DispatchDev::hx0..hy1) -- its
-// primary rays are Misses by construction and are not traced.
-template <bool STATS, bool TLAS, bool DIAG, class E, class NS, class PK>
-__device__ __forceinline__ f3 render_pixel(const SceneDev& sc, const DispatchDev& a, const CamDev& cb, uint32_t x, uint32_t y,
-                                           bool may_hit, E* stk, const NS ns, PK& park, LaneStats& st, const Diag dg)
-{
-    f3 acc = mk3(0.0f, 0.0f, 0.0f);
-    int np = 0;
-    // RayGen: payload {color 0, mask 1, outside true, count 0}, CULL_BACK, [1e-4, 100]
-    f3 O = mk3(cb.cam[0], cb.cam[1], cb.cam[2]);
-    f3 D = camera_ray_dir(cb.M, a.sx[x], a.sy[y]);
-    float w = 1.0f;
-    uint32_t count = 0;
-    bool outside = true;
-    float tmin = a.tmin_p, tmax = a.tmax_p;
-    for (;;) {
-        HitRec h;
-        if (may_hit)
-            trace_scene<STATS, TLAS, E, NS>(sc, O, D, tmin, tmax, outside ? CULL_BACK : CULL_FRONT, h, stk, st.cnt,
-                                            DIAG ? dg : Diag{ nullptr }, ns);
-        else h.hit = false;
-        may_hit = true;
-        ++st.rays;
-        if (STATS && first_active_lane()) ++st.passes;
-        if (DIAG) diag_trip(dg, 2);
-        bool have_next = false;
-        if (!h.hit) {                                             // Miss
-            if (STATS) ++st.miss;
-            f3 e = env_lookup(sc, D);
-            acc.x = fmaf(w, e.x, acc.x); acc.y = fmaf(w, e.y, acc.y); acc.z = fmaf(w, e.z, acc.z);
-        } else {                                                  // ClosestHit
-            if (STATS) ++st.hits;
-            if ((int)count < a.max_refract) {                     // hlsl:82
-                f3 N = shading_normal<TLAS>(sc, h);
-                f3 X = mk3(fmaf(h.t, D.x, O.x), fmaf(h.t, D.y, O.y), fmaf(h.t, D.z, O.z));   // hlsl:88
-                f3 Nf = outside ? N : neg3(N);
-                const float R0 = (0.2f / 2.2f) * (0.2f / 2.2f);   // hlsl:92
-                float b = 1.0f - dot3(D, Nf);                     // hlsl:93, pow(b,5) = b*b*b*b*b
-                float b2 = b * b, b4 = b2 * b2;
-                float R = (R0 * (1.0f - R0)) * (b4 * b);
-                float eta = outside ? a.inv_ior : a.ior;          // hlsl:95
-                f3 d1;
-                bool refr = refract_ray(d1, D, Nf, eta);
-                if (STATS && !refr) ++st.tir;
-                bool refl = (int)count < a.max_reflect;           // hlsl:110
-                f3 d2 = mk3(0.0f, 0.0f, 0.0f);
-                if (refl) d2 = normalize3(reflect_ray(D, Nf));    // hlsl:113
-                const uint32_t c1 = count + 1u;
-                tmin = a.tmin_s; tmax = a.tmax_s;
-                O = X;
-                if (refr) {
-                    if (refl) {                                   // park the reflected child
-                        PendRay p;
-                        p.ox = X.x; p.oy = X.y; p.oz = X.z; p.dx = d2.x; p.dy = d2.y; p.dz = d2.z;
-                        p.w = w * R; p.meta = c1 | (outside ? 0x10000u : 0u);
-                        park.put(np, p);
-                        ++np;
-                    }
-                    D = d1; w = w * (1.0f - R); count = c1; outside = !outside;   // hlsl:103-107
-                    have_next = true;
-                } else if (refl) {
-                    D = d2; w = w * R; count = c1;                                // hlsl:118-122
-                    have_next = true;
-                }
-            } else if (STATS) {
-                ++st.term;                                        // payload.color stays 0
-            }
-        }
-        if (!have_next) {
-            if (np == 0) break;
-            --np;
-            const PendRay p = park.get(np);
-            O = mk3(p.ox, p.oy, p.oz); D = mk3(p.dx, p.dy, p.dz); w = p.w;
-            count = p.meta & 0xffffu; outside = (p.meta & 0x10000u) != 0u;
-            tmin = a.tmin_s; tmax = a.tmax_s;
-        }
-    }
-    return acc;
-}
-
-// RenderTarget[xy] = float4(color,1) -> R8G8B8A8_UNORM (hlsl:62); o: element index inside the slice
-__device__ __forceinline__ void store_pixel(const DispatchDev& a, uint32_t* out_rgba8, float4* out_f32, size_t o, f3 acc)
-{
-    const uint32_t packed = unorm8(acc.x) | (unorm8(acc.y) << 8) | (unorm8(acc.z) << 16) | 0xff000000u;
-    if (a.compact_out == 2u) {               // RGB8 tiles for the gather: alpha is always 255, not worth a link byte
-        uint8_t* p3 = reinterpret_cast<uint8_t*>(out_rgba8) + o * 3;
-        p3[0] = (uint8_t)packed; p3[1] = (uint8_t)(packed >> 8); p3[2] = (uint8_t)(packed >> 16);
-    } else {
-        out_rgba8[o] = packed;
-    }
-    if (out_f32) out_f32[o] = make_float4(acc.x, acc.y, acc.z, 1.0f);
-}
-
-// the wave's tallies -> dispatch counters: one sharded add per wave for the ray count, the rest only in STATS builds
-template <bool STATS>
-__device__ __forceinline__ void flush_stats(const DispatchDev& a, const LaneStats& st, uint32_t shard, uint32_t lane)
-{
-    uint32_t wr = wave_reduce_add(st.rays);
-    if (lane == 0 && wr) atomicAdd(&a.ray_shards[shard & (RAY_SHARDS - 1)], wr);
-    if (STATS) {
-        uint32_t v;
-        v = wave_reduce_add(st.hits);  if (lane == 0 && v) atomicAdd(&a.counters[C_HITS], (unsigned long long)v);
-        v = wave_reduce_add(st.miss);  if (lane == 0 && v) atomicAdd(&a.counters[C_MISSES], (unsigned long long)v);
-        v = wave_reduce_add(st.term);  if (lane == 0 && v) atomicAdd(&a.counters[C_TERMINAL], (unsigned long long)v);
-        v = wave_reduce_add(st.tir);   if (lane == 0 && v) atomicAdd(&a.counters[C_TIR], (unsigned long long)v);
-        v = wave_reduce_add(st.cnt.nodes); if (lane == 0 && v) atomicAdd(&a.counters[C_NODES], (unsigned long long)v);
-        v = wave_reduce_add(st.cnt.tris);  if (lane == 0 && v) atomicAdd(&a.counters[C_TRIS], (unsigned long long)v);
-        v = wave_reduce_add(st.pixels); if (lane == 0 && v) atomicAdd(&a.counters[C_PRIMARY], (unsigned long long)v);
-        v = wave_reduce_add(st.cnt.node_trips); if (lane == 0 && v) atomicAdd(&a.counters[C_NODE_TRIPS], (unsigned long long)v);
-        v = wave_reduce_add(st.cnt.leaf_trips); if (lane == 0 && v) atomicAdd(&a.counters[C_LEAF_TRIPS], (unsigned long long)v);
-        v = wave_reduce_add(st.passes); if (lane == 0 && v) atomicAdd(&a.counters[C_PASSES], (unsigned long long)v);
-        if (lane == 0 && st.blocks) atomicAdd(&a.counters[C_WAVES], (unsigned long long)st.blocks);
-    }
-}
-
-// wave-block wb of the dispatch -> its slice (frame) and the 8x8 pixel block it covers.  Four consecutive wave-blocks are
-// the 32x8 strip one 256-thread workgroup of k_render_fused renders; strips of consecutive frames follow each other (the
-// depth slices are interleaved: mixing the slices keeps every CU on a blend of cheap background waves and expensive mesh
-// waves -- monkey.obj 1080p, Depth 16: 193 us/frame interleaved, 238 us slice after slice).
-struct BlockPos { uint32_t frame, tile_local, x0, y0, px0, py0; bool tile_ok; };
-__device__ __forceinline__ BlockPos wave_block_pos(const DispatchDev& a, uint32_t wb)
-{
-    BlockPos p;
-    const uint32_t blk = wb >> 2, wave = wb & 3u;
-    p.frame = blk % a.n_frames;
-    uint32_t strip;
-    block_to_tile(blk / a.n_frames, p.tile_local, strip);
-    p.tile_ok = p.tile_local < a.n_local_tiles;
-    const uint32_t tile = p.tile_local * a.tile_world + a.tile_rank;
-    const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    p.px0 = wave * 8u; p.py0 = strip * 8u;                         // inside the 32x32 tile
-    p.x0 = tx * TILE + p.px0; p.y0 = ty * TILE + p.py0;
-    return p;
-}
 
 template <int STACK, int PEND, bool STATS, bool TLAS, bool DIAG = false, class E = uint32_t>
 __global__ __launch_bounds__(256, TLAS ? RR_TLAS_WAVES_PER_SIMD(STACK) : sizeof(E) == 2 ? 8 : RR_FUSED_WAVES_PER_SIMD(STACK)) void k_render_fused(SceneDev sc, DispatchDev a)
@@ -419,7 +195,7 @@ __global__ __launch_bounds__(256, 8) void k_render_paths(SceneDev sc, DispatchDe
 // NW waves per workgroup, WGS workgroups per CU (NW * WGS / 4 waves per SIMD); stack entries are 16 bits (node index or
 // 0x8000 | leaf index: an LDS-resident array has fewer than 5 120 nodes).  After the last block the last wave to leave
 // zeroes the ticket words, so the next launch on the same slot needs no memset.
-template <int NW, int WGS, bool STATS, bool DIAG = false, int REGPARK = 0>
+template <int NW, int WGS, bool STATS, bool DIAG = false>
 __global__ __launch_bounds__(NW * 64, NW * WGS / 4) void k_render_lds(SceneDev sc, DispatchDev a, LdsDispatch q)
 {
     typedef uint16_t E;
@@ -440,8 +216,7 @@ __global__ __launch_bounds__(NW * 64, NW * WGS / 4) void k_render_lds(SceneDev s
     const unsigned long long diag_t1 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const LdsNodes ns{ reinterpret_cast<const char*>(lds) };
-    typename std::conditional<REGPARK == 0, MemPark, RegPark<REGPARK == 0 ? 1 : REGPARK> >::type park;
-    if constexpr (REGPARK == 0) park.base = q.park + (size_t)(blockIdx.x * NW + wave) * ((size_t)q.park_slots * 8 * 64) + lane;
+    MemPark park{ q.park + (size_t)(blockIdx.x * NW + wave) * ((size_t)q.park_slots * 8 * 64) + lane };
     E* stk = reinterpret_cast<E*>(reinterpret_cast<char*>(lds) + q.node_bytes) + wave * (q.stack_entries * 64u) + lane;
     const uint32_t lx = compact1by1(lane), ly = compact1by1(lane >> 1);
 
@@ -563,197 +338,6 @@ __global__ __launch_bounds__(NW * 64, NW * WGS / 4) void k_render_lds(SceneDev s
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Lane-asynchronous form of the same renderer, for the reference's scene (one identity instance).
-//
-// k_render_fused keeps the 64 lanes of a wave in lock step: every lane traces "its" ray to the end,
-// then all lanes shade, then all trace the next ray -- so each step costs the slowest lane's
-// traversal (measured on monkey.obj: ~4x more loop trips than the longest lane needs).  Here every
-// lane runs its own pixel's depth-first ray tree as a little state machine (at an internal node /
-// holding a leaf / ray finished, waiting to be shaded) and the WAVE picks, each trip, the phase most
-// of its lanes are waiting for: internal-node step, triangle step or shading step.  Lanes never wait
-// for each other's rays; the expensive shading code runs when a majority needs it.  Arithmetic per
-// ray and the order of a pixel's leaves are unchanged, so results are bit-identical to k_render_fused.
-template <int STACK, int PEND, bool STATS, bool DIAG = false>
-__global__ __launch_bounds__(256) void k_render_async(SceneDev sc, DispatchDev a)
-{
-    const unsigned long long diag_t0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
-    uint32_t diag_trips = 0, diag_tI = 0, diag_tL = 0, diag_tS = 0;
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    uint32_t* stk = lds + wave * (STACK * 64) + lane;
-
-    // Depth slices are interleaved block by block (block b renders slice b % Depth): measured on MI355X,
-    // mixing the slices keeps every CU on a blend of cheap background waves and expensive mesh waves
-    // (monkey.obj 1080p, Depth 16: 193 us/frame interleaved, 238 us slice-after-slice, 747 us at Depth 1).
-    const uint32_t frame = blockIdx.x % a.n_frames;
-    uint32_t tile_local, strip;
-    block_to_tile(blockIdx.x / a.n_frames, tile_local, strip);
-    const bool tile_ok = tile_local < a.n_local_tiles;
-    const uint32_t tile = tile_local * a.tile_world + a.tile_rank;
-    const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    const uint32_t lx = compact1by1(lane), ly = compact1by1(lane >> 1);
-    const uint32_t px = wave * 8u + lx, py = strip * 8u + ly;         // inside the 32x32 tile
-    const uint32_t x = tx * TILE + px, y = ty * TILE + py;
-    const bool valid = tile_ok && x < a.W && y < a.H;
-    const CamDev& cb = a.cams[frame];                                 // wave-uniform: scalar loads
-    uint32_t* const out_rgba8 = a.out_rgba8 + (size_t)frame * a.frame_stride;
-    float4* const out_f32 = a.out_f32 ? a.out_f32 + (size_t)frame * a.frame_stride : nullptr;
-
-    uint32_t n_rays = 0, n_hits = 0, n_miss = 0, n_term = 0, n_tir = 0, n_nodes = 0, n_tris = 0;
-    uint32_t err = 0;
-    const QNode* __restrict__ nodes = sc.blas0.nodes;
-
-    // ---- per-lane state -------------------------------------------------------------------------
-    bool alive = valid;
-    f3 acc = mk3(0.0f, 0.0f, 0.0f);
-    PendRay pend[PEND];
-    int np = 0;
-    f3 O = mk3(cb.cam[0], cb.cam[1], cb.cam[2]);                    // RayGen, RayTracing.hlsl:42-60
-    f3 D = valid ? camera_ray_dir(cb.M, a.sx[x], a.sy[y]) : mk3(1.0f, 0.0f, 0.0f);
-    float w = 1.0f;
-    uint32_t count = 0;
-    bool outside = true;
-    float tmin = a.tmin_p;
-    BoxRay br = box_ray(O, D, sc.blas0.scale, sc.blas0.grid);
-    HitRec h;
-    h.t = a.tmax_p; h.hit = false; h.prim = 0; h.leaf = 0; h.inst = 0; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f;
-    int node = 0;
-    uint32_t* top = stk;
-
-#ifndef RR_SHADE_SHIFT
-#define RR_SHADE_SHIFT 1
-#endif
-    for (;;) {
-        // ---- travel: lanes whose ray is not finished.  The phase ends for the wave once 1/2^RR_SHADE_SHIFT of
-        // them are waiting to be shaded (scalar count of exec, as in trace_blas).
-        const int n_trav = __popcll(__ballot(alive && node != TRAV_DONE));
-        while (alive && node != TRAV_DONE) {
-            {
-                const int part = n_trav >> RR_SHADE_SHIFT;
-                if (__popcll(__ballot(1)) + (part > 1 ? part : 1) <= n_trav) break;
-            }
-            if (DIAG) ++diag_trips;
-            const int n_in = __popcll(__ballot(node >= 0));
-            while (node >= 0) {
-                if (leaf_phase_due(n_in)) break;
-                if (DIAG) ++diag_tI;
-                const NodeQ q = load_node(nodes, node);
-                if (STATS) ++n_nodes;
-                node = node_step(br, q, tmin, h.t, top, stk);
-            }
-            if (node < 0 && node != TRAV_DONE) {
-                if (DIAG) ++diag_tL;
-                if (STATS) ++n_tris;
-                tri_test(sc.blas0.tris, (uint32_t)~node, O, D, tmin, outside ? CULL_BACK : CULL_FRONT, 0u, h);
-                if (top > stk) { top -= STACK_STRIDE; node = (int)*top; } else node = TRAV_DONE;
-            }
-        }
-        {
-            const bool wantS = alive && node == TRAV_DONE;
-            if (DIAG && __ballot(wantS)) ++diag_tS;
-            // ---- shading step: Miss / ClosestHit for every lane whose ray is finished -------------------
-            if (wantS) {
-                ++n_rays;
-                bool have_next = false;
-                if (!h.hit) {                                             // Miss, hlsl:127-137
-                    if (STATS) ++n_miss;
-                    const f3 e = env_lookup(sc, D);
-                    acc.x = fmaf(w, e.x, acc.x); acc.y = fmaf(w, e.y, acc.y); acc.z = fmaf(w, e.z, acc.z);
-                } else {                                                  // ClosestHit, hlsl:79-125
-                    if (STATS) ++n_hits;
-                    if ((int)count < a.max_refract) {
-                        hit_attributes(sc.blas0.tris, O, D, h);
-                        const f3 N = shading_normal<false>(sc, h);
-                        const f3 X = mk3(fmaf(h.t, D.x, O.x), fmaf(h.t, D.y, O.y), fmaf(h.t, D.z, O.z));
-                        const f3 Nf = outside ? N : neg3(N);
-                        const float R0 = (0.2f / 2.2f) * (0.2f / 2.2f);
-                        const float b = 1.0f - dot3(D, Nf);
-                        const float b2 = b * b, b4 = b2 * b2;
-                        const float R = (R0 * (1.0f - R0)) * (b4 * b);
-                        const float eta = outside ? a.inv_ior : a.ior;
-                        f3 d1;
-                        const bool refr = refract_ray(d1, D, Nf, eta);
-                        if (STATS && !refr) ++n_tir;
-                        const bool refl = (int)count < a.max_reflect;
-                        f3 d2 = mk3(0.0f, 0.0f, 0.0f);
-                        if (refl) d2 = normalize3(reflect_ray(D, Nf));
-                        const uint32_t c1 = count + 1u;
-                        O = X;
-                        if (refr) {
-                            if (refl) {
-                                PendRay p;
-                                p.ox = X.x; p.oy = X.y; p.oz = X.z; p.dx = d2.x; p.dy = d2.y; p.dz = d2.z;
-                                p.w = w * R; p.meta = c1 | (outside ? 0x10000u : 0u);
-#pragma unroll
-                                for (int k = 0; k < PEND; ++k) if (k == np) pend[k] = p;
-                                ++np;
-                            }
-                            D = d1; w = w * (1.0f - R); count = c1; outside = !outside;
-                            have_next = true;
-                        } else if (refl) {
-                            D = d2; w = w * R; count = c1;
-                            have_next = true;
-                        }
-                    } else if (STATS) {
-                        ++n_term;
-                    }
-                }
-                if (!have_next && np > 0) {
-                    --np;
-                    PendRay p = pend[0];
-#pragma unroll
-                    for (int k = 1; k < PEND; ++k) if (k == np) p = pend[k];
-                    O = mk3(p.ox, p.oy, p.oz); D = mk3(p.dx, p.dy, p.dz); w = p.w;
-                    count = p.meta & 0xffffu; outside = (p.meta & 0x10000u) != 0u;
-                    have_next = true;
-                }
-                if (have_next) {                                          // TraceRay(child, [1e-3, 1000])
-                    tmin = a.tmin_s;
-                    br = box_ray(O, D, sc.blas0.scale, sc.blas0.grid);
-                    h.t = a.tmax_s; h.hit = false; h.prim = 0; h.leaf = 0; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f;
-                    node = 0; top = stk;
-                } else {                                                  // RenderTarget[xy] = float4(color,1)
-                    const uint32_t packed = unorm8(acc.x) | (unorm8(acc.y) << 8) | (unorm8(acc.z) << 16) | 0xff000000u;
-                    const size_t o = a.compact_out == 0u ? (size_t)y * a.W + x
-                                                         : (size_t)tile_local * (TILE * TILE) + py * TILE + px;
-                    if (a.compact_out == 2u) {
-                        uint8_t* p3 = reinterpret_cast<uint8_t*>(out_rgba8) + o * 3;
-                        p3[0] = (uint8_t)packed; p3[1] = (uint8_t)(packed >> 8); p3[2] = (uint8_t)(packed >> 16);
-                    } else
-                    out_rgba8[o] = packed;
-                    if (out_f32) out_f32[o] = make_float4(acc.x, acc.y, acc.z, 1.0f);
-                    alive = false;
-                }
-            }
-        }
-        if (__ballot(alive) == 0ull) break;
-    }
-
-    if (DIAG) {
-        uint32_t mx = n_rays;
-        for (int off = 32; off > 0; off >>= 1) { uint32_t v = __shfl_xor(mx, off, 64); mx = v > mx ? v : mx; }
-        if (lane == 0) {
-            unsigned long long* d = a.diag + (size_t)(blockIdx.x * 4u + wave) * 4;
-            d[0] = ((unsigned long long)diag_tI << 40) | ((unsigned long long)diag_tL << 20) | diag_tS;
-            d[1] = __builtin_amdgcn_s_memtime() - diag_t0; d[2] = mx; d[3] = diag_trips;
-        }
-    }
-    uint32_t wr = wave_reduce_add(n_rays);
-    if (lane == 0 && wr) atomicAdd(&a.ray_shards[(blockIdx.x * 4u + wave) & (RAY_SHARDS - 1)], wr);
-    if (err) atomicOr(a.error_flag, 1u);
-    if (STATS) {
-        uint32_t v;
-        v = wave_reduce_add(n_hits);  if (lane == 0 && v) atomicAdd(&a.counters[C_HITS], (unsigned long long)v);
-        v = wave_reduce_add(n_miss);  if (lane == 0 && v) atomicAdd(&a.counters[C_MISSES], (unsigned long long)v);
-        v = wave_reduce_add(n_term);  if (lane == 0 && v) atomicAdd(&a.counters[C_TERMINAL], (unsigned long long)v);
-        v = wave_reduce_add(n_tir);   if (lane == 0 && v) atomicAdd(&a.counters[C_TIR], (unsigned long long)v);
-        v = wave_reduce_add(n_nodes); if (lane == 0 && v) atomicAdd(&a.counters[C_NODES], (unsigned long long)v);
-        v = wave_reduce_add(n_tris);  if (lane == 0 && v) atomicAdd(&a.counters[C_TRIS], (unsigned long long)v);
-        v = wave_reduce_add(valid ? 1u : 0u); if (lane == 0 && v) atomicAdd(&a.counters[C_PRIMARY], (unsigned long long)v);
-    }
-}
-
 // GenerateCameraRay's per-column and per-row screen coordinates (RayTracing.hlsl:29-33): out[0..W) = sx, out[W..W+H) = sy
 __global__ __launch_bounds__(256) void k_screen_tables(float* out, uint32_t W, uint32_t H)
 {
@@ -863,188 +447,6 @@ __global__ __launch_bounds__(256) void k_assemble_frames_rgb8(const uint8_t* __r
 }
 
 
-// ---------------------------------------------------------------------------------------------------
-// Experimental queue-per-bounce ("wavefront path tracing") form of the same renderer, for comparison with the
-// fused kernel (RR_DEBUG_KERNEL=wavefront).  One kernel per ray generation: rays of bounce g are read from a queue,
-// traced and shaded; children go to the queue of bounce g+1 (one atomic per wave and child kind).  A pixel's ray
-// tree branches only while count < max_reflect, so with max_reflect <= 2 it has at most four leaves; leaf k (in the
-// recursion's depth-first order: refraction before reflection) writes its (weight, texel) to slot k of the pixel, and
-// a last kernel sums the four slots in order -- the same fma sequence as the fused kernel, bit for bit, whatever
-// order the queues were filled in.
-struct WfRay { f3 O, D; float w; uint32_t pix, count, slot; bool outside; };
-
-__device__ __forceinline__ void wf_store(float4* q, uint32_t i, const WfRay& r)
-{
-    q[(size_t)i * 3 + 0] = make_float4(r.O.x, r.O.y, r.O.z, r.w);
-    q[(size_t)i * 3 + 1] = make_float4(r.D.x, r.D.y, r.D.z, __uint_as_float(r.pix));
-    q[(size_t)i * 3 + 2] = make_float4(__uint_as_float(r.count | (r.outside ? 0x10000u : 0u) | (r.slot << 20)), 0.0f, 0.0f, 0.0f);
-}
-__device__ __forceinline__ WfRay wf_load(const float4* q, uint32_t i)
-{
-    const float4 a = q[(size_t)i * 3 + 0], b = q[(size_t)i * 3 + 1], c = q[(size_t)i * 3 + 2];
-    WfRay r;
-    r.O = mk3(a.x, a.y, a.z); r.w = a.w; r.D = mk3(b.x, b.y, b.z); r.pix = __float_as_uint(b.w);
-    const uint32_t m = __float_as_uint(c.x);
-    r.count = m & 0xffffu; r.outside = (m & 0x10000u) != 0u; r.slot = m >> 20;
-    return r;
-}
-// append the rays of the lanes with `have` set: one atomic per wave
-__device__ __forceinline__ void wf_push(const WfBuffers& wf, int gen, bool have, const WfRay& r, uint32_t* err)
-{
-    const unsigned long long m = __ballot(have);
-    if (m == 0ull) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const int first = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if ((int)lane == first) base = atomicAdd(&wf.counts[gen], (uint32_t)__popcll(m));
-    base = __shfl(base, first, 64);
-    const uint32_t idx = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (have) { if (idx < wf.cap) wf_store(wf.q[gen & 1], idx, r); else *err = 1u; }
-}
-
-// ClosestHit for one lane: emits up to two children (refracted first).  Returns false for a terminal hit.
-__device__ __forceinline__ void wf_shade_hit(const SceneDev& sc, const DispatchDev& a, const WfRay& in, const HitRec& h,
-                                             bool& refr, bool& refl, WfRay& c1, WfRay& c2)
-{
-    refr = false; refl = false;
-    if ((int)in.count >= a.max_refract) return;                       // hlsl:82 (payload.color stays 0)
-    const f3 N = shading_normal<false>(sc, h);
-    const f3 X = mk3(fmaf(h.t, in.D.x, in.O.x), fmaf(h.t, in.D.y, in.O.y), fmaf(h.t, in.D.z, in.O.z));
-    const f3 Nf = in.outside ? N : neg3(N);
-    const float R0 = (0.2f / 2.2f) * (0.2f / 2.2f);
-    const float b = 1.0f - dot3(in.D, Nf);
-    const float b2 = b * b, b4 = b2 * b2;
-    const float R = (R0 * (1.0f - R0)) * (b4 * b);
-    const float eta = in.outside ? a.inv_ior : a.ior;
-    f3 d1;
-    refr = refract_ray(d1, in.D, Nf, eta);
-    refl = (int)in.count < a.max_reflect;
-    f3 d2 = mk3(0.0f, 0.0f, 0.0f);
-    if (refl) d2 = normalize3(reflect_ray(in.D, Nf));
-    const uint32_t bit = in.count < 2u ? (2u >> in.count) : 0u;       // the reflected branch at depth 0 / 1 owns slots 2,3 / 1,3
-    c1.O = X; c1.D = d1; c1.pix = in.pix; c1.count = in.count + 1u; c1.slot = in.slot;
-    c2.O = X; c2.D = d2; c2.pix = in.pix; c2.count = in.count + 1u; c2.slot = in.slot | bit; c2.outside = in.outside;
-    if (refr) { c1.w = in.w * (1.0f - R); c1.outside = !in.outside; c2.w = in.w * R; }
-    else { c1.w = 0.0f; c1.outside = in.outside; c2.w = in.w * R; }
-}
-
-template <int STACK>
-__global__ __launch_bounds__(256, RR_FUSED_WAVES_PER_SIMD(STACK)) void k_wf_primary(SceneDev sc, DispatchDev a, WfBuffers wf)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    uint32_t* stk = lds + wave * (STACK * 64) + lane;
-    const uint32_t frame = blockIdx.x % a.n_frames;
-    uint32_t tile_local, strip;
-    block_to_tile(blockIdx.x / a.n_frames, tile_local, strip);
-    const bool tile_ok = tile_local < a.n_local_tiles;
-    const uint32_t tile = tile_local * a.tile_world + a.tile_rank;
-    const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    const uint32_t lx = compact1by1(lane), ly = compact1by1(lane >> 1);
-    const uint32_t px = wave * 8u + lx, py = strip * 8u + ly;
-    const uint32_t x = tx * TILE + px, y = ty * TILE + py;
-    const bool valid = tile_ok && x < a.W && y < a.H;
-    const CamDev& cb = a.cams[frame];
-    uint32_t err = 0;
-    bool refr = false, refl = false;
-    WfRay c1, c2;
-    c1.O = c1.D = c2.O = c2.D = mk3(0.0f, 0.0f, 0.0f); c1.w = c2.w = 0.0f; c1.pix = c2.pix = 0u; c1.count = c2.count = 0u;
-    c1.slot = c2.slot = 0u; c1.outside = c2.outside = true;
-    if (valid) {
-        WfRay r;
-        r.O = mk3(cb.cam[0], cb.cam[1], cb.cam[2]);
-        r.D = camera_ray_dir(cb.M, a.sx[x], a.sy[y]);
-        r.w = 1.0f; r.count = 0u; r.slot = 0u; r.outside = true;
-        r.pix = (uint32_t)((size_t)frame * a.frame_stride + (size_t)y * a.W + x);
-        HitRec h;
-        TravCounters cnt; cnt.nodes = 0; cnt.tris = 0;
-        trace_scene<false, false>(sc, r.O, r.D, a.tmin_p, a.tmax_p, CULL_BACK, h, stk, cnt);
-        if (!h.hit) {                                            // the pixel's only leaf: acc = fma(1, texel, 0)
-            const f3 e = env_lookup(sc, r.D);
-            const f3 acc = mk3(fmaf(1.0f, e.x, 0.0f), fmaf(1.0f, e.y, 0.0f), fmaf(1.0f, e.z, 0.0f));
-            a.out_rgba8[r.pix] = unorm8(acc.x) | (unorm8(acc.y) << 8) | (unorm8(acc.z) << 16) | 0xff000000u;
-        } else {
-            wf_shade_hit(sc, a, r, h, refr, refl, c1, c2);
-            if (!refr && !refl) a.out_rgba8[r.pix] = 0xff000000u;                    // no child: black
-            else {
-                const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                float4* sl = wf.slots + (size_t)r.pix * 4;
-                sl[0] = z; sl[1] = z; sl[2] = z; sl[3] = z;
-            }
-        }
-    }
-    // covered pixels and their children (wave-aggregated appends)
-    {
-        const bool cov = refr || refl;
-        const unsigned long long m = __ballot(cov);
-        if (m) {
-            const int first = __ffsll((long long)m) - 1;
-            uint32_t base = 0;
-            if ((int)lane == first) base = atomicAdd(&wf.counts[63], (uint32_t)__popcll(m));
-            base = __shfl(base, first, 64);
-            if (cov) wf.hit_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = c2.pix;
-        }
-    }
-    wf_push(wf, 1, refr, c1, &err);
-    wf_push(wf, 1, refl, c2, &err);
-    if (err) atomicOr(a.error_flag, 1u);
-}
-
-template <int STACK>
-__global__ __launch_bounds__(256, RR_FUSED_WAVES_PER_SIMD(STACK)) void k_wf_bounce(SceneDev sc, DispatchDev a, WfBuffers wf, int gen)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    uint32_t* stk = lds + wave * (STACK * 64) + lane;
-    uint32_t n = wf.counts[gen];
-    n = n < wf.cap ? n : wf.cap;
-    const float4* qin = wf.q[gen & 1];
-    uint32_t err = 0;
-    for (uint32_t base = (blockIdx.x * 4u + wave) * 64u; base < n; base += gridDim.x * 256u) {
-        const uint32_t i = base + lane;
-        bool refr = false, refl = false;
-        WfRay c1, c2;
-        c1.O = c1.D = c2.O = c2.D = mk3(0.0f, 0.0f, 0.0f); c1.w = c2.w = 0.0f; c1.pix = c2.pix = 0u; c1.count = c2.count = 0u;
-        c1.slot = c2.slot = 0u; c1.outside = c2.outside = true;
-        if (i < n) {
-            const WfRay r = wf_load(qin, i);
-            HitRec h;
-            TravCounters cnt; cnt.nodes = 0; cnt.tris = 0;
-            trace_scene<false, false>(sc, r.O, r.D, a.tmin_s, a.tmax_s, r.outside ? CULL_BACK : CULL_FRONT, h, stk, cnt);
-            if (!h.hit) {
-                const f3 e = env_lookup(sc, r.D);
-                wf.slots[(size_t)r.pix * 4 + r.slot] = make_float4(r.w, e.x, e.y, e.z);
-            } else {
-                wf_shade_hit(sc, a, r, h, refr, refl, c1, c2);
-            }
-        }
-        wf_push(wf, gen + 1, refr, c1, &err);
-        wf_push(wf, gen + 1, refl, c2, &err);
-    }
-    if (err) atomicOr(a.error_flag, 1u);
-}
-
-__global__ __launch_bounds__(256) void k_wf_resolve(DispatchDev a, WfBuffers wf)
-{
-    const uint32_t n = wf.counts[63];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {                   // TraceRay calls of the dispatch: primaries + every queued ray
-        uint32_t rays = a.W * a.H * a.n_frames;
-        for (int g = 1; g < 63; ++g) rays += wf.counts[g];
-        atomicAdd(&a.ray_shards[0], rays);
-    }
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const uint32_t pix = wf.hit_list[i];
-        const float4* sl = wf.slots + (size_t)pix * 4;
-        f3 acc = mk3(0.0f, 0.0f, 0.0f);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float4 s = sl[k];                              // an unused slot holds w = 0: fma(0, 0, acc) == acc
-            acc.x = fmaf(s.x, s.y, acc.x); acc.y = fmaf(s.x, s.z, acc.y); acc.z = fmaf(s.x, s.w, acc.z);
-        }
-        a.out_rgba8[pix] = unorm8(acc.x) | (unorm8(acc.y) << 8) | (unorm8(acc.z) << 16) | 0xff000000u;
-    }
-}
-
 // ------------------------------------------------------------------------------------ launchers
 template <int STACK, int PEND, bool TLAS>
 static hipError_t launch_fused_spt(const SceneDev& sc, const DispatchDev& a, bool stats, hipStream_t s)
@@ -1052,15 +454,6 @@ static hipError_t launch_fused_spt(const SceneDev& sc, const DispatchDev& a, boo
     const size_t lds = (size_t)4 * STACK * 64 * sizeof(uint32_t);
     if (stats) hipLaunchKernelGGL((k_render_fused<STACK, PEND, true, TLAS>), dim3(a.n_blocks), dim3(256), lds, s, sc, a);
     else       hipLaunchKernelGGL((k_render_fused<STACK, PEND, false, TLAS>), dim3(a.n_blocks), dim3(256), lds, s, sc, a);
-    return hipGetLastError();
-}
-
-template <int STACK, int PEND>
-static hipError_t launch_async_sp(const SceneDev& sc, const DispatchDev& a, bool stats, hipStream_t s)
-{
-    const size_t lds = (size_t)4 * STACK * 64 * sizeof(uint32_t);
-    if (stats) hipLaunchKernelGGL((k_render_async<STACK, PEND, true>), dim3(a.n_blocks), dim3(256), lds, s, sc, a);
-    else       hipLaunchKernelGGL((k_render_async<STACK, PEND, false>), dim3(a.n_blocks), dim3(256), lds, s, sc, a);
     return hipGetLastError();
 }
 
@@ -1121,25 +514,16 @@ hipError_t launch_render_lds(const SceneDev& sc, const DispatchDev& a, LdsDispat
         hipLaunchKernelGGL((k_render_lds<12, 2, false, true>), dim3((uint32_t)n_cus * 2), dim3(12 * 64), l12, s, sc, a, q);
         return hipGetLastError();
     }
-    if (q.dbg_regpark && shape == 1 && q.park_slots <= 2u && !stats) {      // experiment: parked rays in registers
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_lds<16, 2, false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-        if (attr != hipSuccess) return attr;
-        hipLaunchKernelGGL((k_render_lds<16, 2, false, false, 2>), dim3((uint32_t)n_cus * 2), dim3(16 * 64), lds, s, sc, a, q);
-        return hipGetLastError();
-    }
     if (shape == 0) return launch_lds_nw<12, 2>(sc, a, q, lds, n_cus, stats, s);
     if (shape == 1) return launch_lds_nw<16, 2>(sc, a, q, lds, n_cus, stats, s);
     return launch_lds_nw<16, 1>(sc, a, q, lds, n_cus, stats, s);
 }
 
-// default: the lock-step kernel (best throughput once several slices are in flight); async: the lane-asynchronous one
-// (RR_DEBUG_KERNEL=async, read by rr_create: shorter worst wave on irregular meshes, costlier trips)
 template <int STACK, int PEND>
-static hipError_t launch_fused_sp(const SceneDev& sc, const DispatchDev& a, bool stats, hipStream_t s, bool async)
+static hipError_t launch_fused_sp(const SceneDev& sc, const DispatchDev& a, bool stats, hipStream_t s)
 {
     if (!sc.single_identity) return launch_fused_spt<STACK, PEND, true>(sc, a, stats, s);
-    if (!async) return launch_fused_spt<STACK, PEND, false>(sc, a, stats, s);
-    return launch_async_sp<STACK, PEND>(sc, a, stats, s);
+    return launch_fused_spt<STACK, PEND, false>(sc, a, stats, s);
 }
 
 // reference-scene kernel on 16-bit stack entries (meshes below 32 768 triangles, trees of 20..39 levels): 39 entries are
@@ -1153,22 +537,21 @@ static hipError_t launch_fused_s16(const SceneDev& sc, const DispatchDev& a, boo
     return hipGetLastError();
 }
 
-hipError_t launch_render_fused(const SceneDev& sc, const DispatchDev& a, int stack, int pend, bool stats, hipStream_t s, bool stack16, bool async)
+hipError_t launch_render_fused(const SceneDev& sc, const DispatchDev& a, int stack, int pend, bool stats, hipStream_t s, bool stack16)
 {
     if (a.n_blocks == 0) return hipSuccess;
-    if (stack16 && !a.diag && sc.single_identity && !async && stack <= 39)
+    if (stack16 && !a.diag && sc.single_identity && stack <= 39)
         return pend <= 2 ? launch_fused_s16<2>(sc, a, stats, s) : launch_fused_s16<8>(sc, a, stats, s);
-    if (a.diag) {       // diagnostic builds of the reference-scene kernels (never used by the product path)
-        if (!async) hipLaunchKernelGGL((k_render_fused<31, 2, false, false, true>), dim3(a.n_blocks), dim3(256), 4 * 31 * 64 * 4, s, sc, a);
-        else hipLaunchKernelGGL((k_render_async<31, 2, false, true>), dim3(a.n_blocks), dim3(256), 4 * 31 * 64 * 4, s, sc, a);
+    if (a.diag) {       // diagnostic build of the reference-scene kernel (RR_DEBUG_DIAG; never used by the product path)
+        hipLaunchKernelGGL((k_render_fused<31, 2, false, false, true>), dim3(a.n_blocks), dim3(256), 4 * 31 * 64 * 4, s, sc, a);
         return hipGetLastError();
     }
-    if (stack <= 19 && pend <= 2) return launch_fused_sp<19, 2>(sc, a, stats, s, async);
-    if (stack <= 22 && pend <= 2) return launch_fused_sp<22, 2>(sc, a, stats, s, async);
-    if (stack <= 26 && pend <= 2) return launch_fused_sp<26, 2>(sc, a, stats, s, async);
-    if (stack <= 31) return pend <= 2 ? launch_fused_sp<31, 2>(sc, a, stats, s, async) : launch_fused_sp<31, 8>(sc, a, stats, s, async);
-    if (stack <= 39) return pend <= 2 ? launch_fused_sp<39, 2>(sc, a, stats, s, async) : launch_fused_sp<39, 8>(sc, a, stats, s, async);
-    return pend <= 2 ? launch_fused_sp<64, 2>(sc, a, stats, s, async) : launch_fused_sp<64, 8>(sc, a, stats, s, async);
+    if (stack <= 19 && pend <= 2) return launch_fused_sp<19, 2>(sc, a, stats, s);
+    if (stack <= 22 && pend <= 2) return launch_fused_sp<22, 2>(sc, a, stats, s);
+    if (stack <= 26 && pend <= 2) return launch_fused_sp<26, 2>(sc, a, stats, s);
+    if (stack <= 31) return pend <= 2 ? launch_fused_sp<31, 2>(sc, a, stats, s) : launch_fused_sp<31, 8>(sc, a, stats, s);
+    if (stack <= 39) return pend <= 2 ? launch_fused_sp<39, 2>(sc, a, stats, s) : launch_fused_sp<39, 8>(sc, a, stats, s);
+    return pend <= 2 ? launch_fused_sp<64, 2>(sc, a, stats, s) : launch_fused_sp<64, 8>(sc, a, stats, s);
 }
 
 template <int STACK, bool TLAS>
@@ -1251,25 +634,5 @@ hipError_t launch_assemble_frames_rgb8(const uint8_t* gathered, uint32_t* frames
 }
 
 
-template <int STACK>
-static hipError_t launch_wavefront_s(const SceneDev& sc, const DispatchDev& a, const WfBuffers& wf, hipStream_t s)
-{
-    const size_t lds = (size_t)4 * STACK * 64 * sizeof(uint32_t);
-    hipError_t e = hipMemsetAsync(wf.counts, 0, 64 * sizeof(uint32_t), s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_wf_primary<STACK>), dim3(a.n_blocks), dim3(256), lds, s, sc, a, wf);
-    const uint32_t persistent = 256u * 6u;
-    for (int g = 1; g <= a.max_refract && g < 62; ++g)
-        hipLaunchKernelGGL((k_wf_bounce<STACK>), dim3(persistent), dim3(256), lds, s, sc, a, wf, g);
-    hipLaunchKernelGGL(k_wf_resolve, dim3(persistent), dim3(256), 0, s, a, wf);
-    return hipGetLastError();
-}
-
-hipError_t launch_render_wavefront(const SceneDev& sc, const DispatchDev& a, const WfBuffers& wf, int stack, hipStream_t s)
-{
-    if (stack <= 26) return launch_wavefront_s<26>(sc, a, wf, s);
-    if (stack <= 31) return launch_wavefront_s<31>(sc, a, wf, s);
-    return launch_wavefront_s<64>(sc, a, wf, s);
-}
 
 } // namespace rr

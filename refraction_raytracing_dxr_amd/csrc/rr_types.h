@@ -146,7 +146,6 @@ struct LdsDispatch {
     uint32_t wave_blocks;       // 4 per 32x8 strip block of the dispatch
     uint32_t n_queues;          // ticket queues per phase in use (<= LDS_QUEUES)
     uint32_t home_xcc;          // 1: a wave's first queue is its XCD's number, 0: its own number, modulo n_queues
-    uint32_t dbg_regpark;       // experiments: parked rays in registers
     uint32_t* park;             // parked reflected rays: [wave of the grid][park_slots][8 words][64 lanes]
     uint32_t park_slots;        // >= max_reflect
     uint32_t node_bytes;        // size of the node array copied to LDS (multiple of 32)

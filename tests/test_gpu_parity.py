@@ -30,6 +30,14 @@ def gpu():
     r.close()
 
 
+def experimental_build():
+    """True when librrdxr.so was built with RR_EXPERIMENTAL=1 (the render-kernel experiments of csrc/rr_render_exp.hip)."""
+    try:
+        return "-DRR_EXPERIMENTAL" in open(os.path.join(ROOT, "refraction_raytracing_dxr_amd", "build", "flags.txt")).read()
+    except OSError:
+        return False
+
+
 def load(name):
     m = rr.Mesh()
     assert m.load(O.asset(name))
@@ -245,6 +253,7 @@ def test_out_of_range_texel_through_dispatch_rays(gpu):
         assert rgba[0, 0, 0] == (0 if expect == 0.0 else 191)
 
 
+@pytest.mark.skipif(not experimental_build(), reason="the product library does not contain the experiments (build with RR_EXPERIMENTAL=1)")
 def test_experimental_wavefront_kernels_render_the_same_frames(tmp_path):
     """RR_DEBUG_KERNEL=wavefront (queue-per-bounce kernels kept for comparison): bit-identical frames to
     the fused kernel, whatever order the queues fill in.  Own processes: the switch is read once per process."""
@@ -302,7 +311,8 @@ def test_lds_and_path_parallel_kernels_render_the_same_frames(tmp_path):
         "np.save(sys.argv[1], np.stack(out)); print(' '.join(str(c) for c in cnt))\n") % ROOT
     res = {}
     for k, extra in (("fused", {}), ("lds", {}), ("lds", {"RR_DEBUG_SHAPE": "1"}), ("lds", {"RR_DEBUG_SHAPE": "2", "RR_DEBUG_TICKET": "19"}),
-                     ("paths", {})):            # k_render_paths: four lanes per pixel, leaves summed in the recursion's order
+                     ("paths", {})) + (         # k_render_paths: four lanes per pixel, leaves summed in the recursion's order
+                     (("refill", {}),) if experimental_build() else ()):     # experiment, same bar
         env = dict(os.environ, RR_DEBUG_KERNEL=k, **extra)
         tag = k + "".join(extra.values())
         p = subprocess.run([sys.executable, "-c", code, str(tmp_path / (tag + ".npy"))], capture_output=True, text=True, env=env, timeout=600)

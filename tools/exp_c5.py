@@ -18,6 +18,9 @@ W, H = 3840, 2160
 r.dispatch_rays(W, H, rr.default_params(max_refract=16, flags=rr.DISPATCH_COLLECT_STATS))
 st = r.stats()
 print("rays %.2fM  rays/px %.2f  nodes/ray %.1f  tris/ray %.2f  hits %.2fM  depth %d" % (st.rays / 1e6, st.rays / (W * H), st.node_visits / st.rays, st.tri_tests / st.rays, st.hits / 1e6, st.bvh_depth))
+print("wave trips: node %.2fM leaf %.2fM passes %.3fM waves %.3fM | lane utilisation node %.1f %% leaf(tri) %.1f %% pass %.1f %%" % (
+    st.node_trips / 1e6, st.leaf_trips / 1e6, st.shade_passes / 1e6, st.waves / 1e6, 100 * st.node_visits / (64.0 * st.node_trips),
+    100 * st.tri_tests / (64.0 * st.leaf_trips), 100 * st.rays / (64.0 * st.shade_passes)))
 p = rr.default_params(max_refract=16, flags=rr.DISPATCH_TIME_KERNEL)
 for _ in range(3): r.dispatch_rays(W, H, p)
 ms, n = r.kernel_time()
