@@ -142,7 +142,10 @@ int  rr_reset_stream(rr_context* ctx);
 int  rr_wait(rr_context* ctx);
 
 /* ---- assets -> device -------------------------------------------------------------------- */
-/* Mesh::upload, Mesh.cpp:55-94 (+ geometry desc Mesh.cpp:39-53): copies; caller keeps ownership. */
+/* Mesh::upload, Mesh.cpp:55-94 (+ geometry desc Mesh.cpp:39-53): copies; caller keeps ownership.
+ * Positions must be finite and no larger than 1e18 in magnitude (rr_host_validate_positions): the BLAS builder works
+ * with box areas in fp32 -- a D3D12 driver is free to produce garbage for such input, this library returns
+ * RR_ERR_INVALID_ARGUMENT instead.  (Mesh::load itself accepts "v 1e39 0 0": strtof turns it into +inf.) */
 int  rr_upload_mesh(rr_context* ctx, const rr_vertex* verts, uint32_t n_verts,
                     const uint32_t* indices, uint32_t n_indices, uint32_t* mesh_id);
 /* load_texture, RefractionDemo.cpp:108-140: tightly packed RGB32F, row pitch w*12 (:128). */
@@ -309,6 +312,9 @@ float* rr_host_image_loadf(const char* filename, int* x, int* y, int* channels_i
 /* Radiance RLE .hdr writer (the reference's envmap.hdr is missing from the mount). */
 int  rr_host_image_write_hdr(const char* filename, int w, int h, const float* rgb);
 void rr_host_free(void* p);
+/* RR_OK if every position of the n vertices is finite and |x|, |y|, |z| <= 1e18 (what rr_upload_mesh requires),
+ * RR_ERR_INVALID_ARGUMENT otherwise; *first_bad (may be NULL) receives the index of the first offending vertex. */
+int  rr_host_validate_positions(const rr_vertex* verts, uint32_t n_verts, uint32_t* first_bad);
 uint32_t rr_abi_version(void);
 
 #ifdef __cplusplus

@@ -119,6 +119,7 @@ SYMBOLS = {
     "rr_host_image_loadf": (_P, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
     "rr_host_image_write_hdr": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _P]),
     "rr_host_free": (None, [_P]),
+    "rr_host_validate_positions": (C.c_int, [_P, C.c_uint32, _P]),
 }
 
 _lib = None

@@ -192,3 +192,18 @@ static int load_obj_impl(const char* filename, uint32_t flags, rr_vertex** verts
 }
 
 extern "C" void rr_host_free(void* p) { free(p); }
+
+// what rr_upload_mesh requires of positions: finite, |coordinate| <= 1e18 (box areas stay finite in fp32)
+extern "C" int rr_host_validate_positions(const rr_vertex* verts, uint32_t n_verts, uint32_t* first_bad)
+{
+    if (!verts && n_verts) return RR_ERR_INVALID_ARGUMENT;
+    for (uint32_t i = 0; i < n_verts; ++i)
+        for (int k = 0; k < 3; ++k) {
+            const float v = verts[i].position[k];
+            if (!(std::fabs(v) <= 1e18f)) {            // false for NaN and infinities too
+                if (first_bad) *first_bad = i;
+                return RR_ERR_INVALID_ARGUMENT;
+            }
+        }
+    return RR_OK;
+}

@@ -281,6 +281,7 @@ __global__ __launch_bounds__(1024) void k_ploc(BuildBuffers b)
     __syncthreads();
     int m = n;
     int next_id = n - 2;                              // internal ids are handed out downwards: the last merge is node 0
+    bool force_pair = false;
     while (m > 1) {
         // 1. nearest neighbour of every cluster within the radius
         for (int i = tid; i < m; i += 1024) {
@@ -291,10 +292,12 @@ __global__ __launch_bounds__(1024) void k_ploc(BuildBuffers b)
             for (int j = j0; j <= j1; ++j) {
                 if (j == i) continue;
                 const float a = merged_area(bu, b.node_box + (size_t)A[j] * 6);
-                if (a < best) { best = a; bj = j; }
+                if (bj < 0 || a < best) { best = a; bj = j; }     // total: the first candidate stands unless a smaller area turns up (areas that overflow or are NaN compare false)
             }
-            NN[i] = bj;
+            NN[i] = bj;                                            // m >= 2: there is always a candidate
         }
+        __syncthreads();
+        if (force_pair && tid == 0) { NN[0] = 1; NN[1] = 0; }      // the round before merged nothing: clusters 0 and 1 merge now
         __syncthreads();
         // 2. mutual pairs merge (the lower position keeps the new cluster), everything else survives as is
         const int chunk = (m + 1023) / 1024;
@@ -333,6 +336,7 @@ __global__ __launch_bounds__(1024) void k_ploc(BuildBuffers b)
         }
         next_id -= (int)(total >> 16);
         m = (int)(total & 0xffffu);
+        force_pair = (total >> 16) == 0u;             // no mutual pair (possible only among equal or unordered areas): never loop without progress
         __syncthreads();
         uint32_t* t = A; A = B; B = t;
         __syncthreads();

@@ -455,6 +455,8 @@ int rr_upload_mesh(rr_context* ctx, const rr_vertex* verts, uint32_t n_verts, co
         return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_upload_mesh: need >= 1 triangle, n_indices % 3 == 0");
     for (uint32_t i = 0; i < n_indices; ++i)
         if (indices[i] >= n_verts) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_upload_mesh: index out of range");
+    if (rr_host_validate_positions(verts, n_verts, nullptr) != RR_OK)
+        return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_upload_mesh: non-finite or huge (> 1e18) vertex position");
     MeshRes m;
     m.n_verts = n_verts; m.n_idx = n_indices; m.n_tris = n_indices / 3;
     RR_HIP(hipMalloc(&m.d_verts, (size_t)n_verts * sizeof(rr_vertex)));

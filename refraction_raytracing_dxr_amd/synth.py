@@ -3,7 +3,8 @@ import os
 
 import numpy as np
 
-ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "assets")
+# package data: byte-identical copies of the reference's data files (cube / sphere / monkey / shell / ott .obj, envmap.png)
+ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
 
 
 def asset(name):

@@ -36,7 +36,7 @@ def pytest_collection_modifyitems(config, items):
 def env_png():
     """envmap.png decoded by the product loader (640x480 RGB32F, gamma-expanded)"""
     import refraction_raytracing_dxr_amd as rr
-    env, _ = rr.load_texture(os.path.join(ROOT, "tests", "golden", "assets", "envmap.png"), 3)
+    env, _ = rr.load_texture(os.path.join(ROOT, "refraction_raytracing_dxr_amd", "assets", "envmap.png"), 3)
     return env
 
 

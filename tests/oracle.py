@@ -11,7 +11,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ASSETS = os.path.join(ROOT, "tests", "golden", "assets")
+ASSETS = os.path.join(ROOT, "refraction_raytracing_dxr_amd", "assets")      # the reference's data files, shipped as package data
 
 CULL_BACK = 0x10
 CULL_FRONT = 0x20

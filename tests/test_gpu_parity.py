@@ -323,6 +323,41 @@ def test_lds_and_path_parallel_kernels_render_the_same_frames(tmp_path):
         assert res["fused"][1] == res[tag][1], tag
 
 
+def test_ploc_builder_makes_progress_on_equal_and_overflowing_areas(gpu):
+    """The PREFER_FAST_TRACE builder merges mutually nearest clusters by merged-box area.  Identical triangles (every
+    candidate area equal), a regular lattice (ties everywhere) and coordinates of 1e18 (areas near the top of fp32) must all
+    build and trace like brute force: the neighbour search is total and a round without a mutual pair forces one."""
+    rng = np.random.default_rng(5)
+    tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    cases = {
+        "identical": np.tile(tri, (40, 1)),
+        "lattice": np.concatenate([tri + np.array([i, j, 0], np.float32) * 2 for i in range(7) for j in range(7)]),
+        "huge": np.concatenate([tri * np.float32(1e17) + np.array([i, 0, 0], np.float32) * np.float32(8e17) for i in range(2)]),
+    }
+    for name, pos in cases.items():
+        v = np.zeros(len(pos), rr.VERTEX_DTYPE)
+        v["position"] = pos
+        v["norm"] = (0, 0, 1)
+        idx = np.arange(len(pos), dtype=np.uint32)
+        mid = gpu.upload_mesh(v, idx)
+        gpu.build_blas(mid)
+        gpu.build_tlas(rr.make_instances(meshes=[mid]))
+        s = O.Scene(); s.add_mesh(v, idx)
+        scale = float(np.abs(pos).max())
+        rays = np.zeros(300, rr.RAY_DTYPE)
+        rays["origin"] = (rng.random((300, 3)).astype(np.float32) * 2 - 0.5) * np.float32(scale * 0.6) + np.array([0, 0, scale], np.float32)
+        d = rng.standard_normal((300, 3)).astype(np.float32); d[:, 2] = -np.abs(d[:, 2]) - 1.0
+        rays["dir"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+        rays["tmin"] = 0.0; rays["tmax"] = np.float32(scale * 100)
+        rays["flags"] = 0
+        hits = gpu.trace_rays(rays)
+        for k in range(300):
+            h = s.trace(rays["origin"][k], rays["dir"][k], 0.0, float(rays["tmax"][k]), 0, use_bvh=0)
+            assert bool(hits["hit"][k]) == bool(h.hit), (name, k)
+            if h.hit:
+                assert hits["t"][k] == np.float32(h.t) and hits["prim"][k] == h.prim, (name, k)
+
+
 def test_builds_are_deterministic(gpu):
     """same mesh, two builds: identical fp32 and quantised hierarchies (the PLOC merge order comes from scans,
     the Karras tree from sorted unique keys; nothing depends on atomics order)"""
@@ -664,6 +699,13 @@ def test_error_behaviour():
         r.upload_mesh(v, np.array([0, 1, 5], np.uint32))         # index out of range
     with pytest.raises(rr.RRError):
         r.upload_mesh(v, np.array([0, 1], np.uint32))            # not a triangle list
+    for val in (np.inf, np.nan, 1e20):                           # a position the builder's box areas cannot hold: an error, not a hung build
+        bad = np.zeros(6, rr.VERTEX_DTYPE)
+        bad["position"] = np.random.default_rng(1).random((6, 3)).astype(np.float32)
+        bad["position"][4, 2] = val
+        with pytest.raises(rr.RRError) as e:
+            r.upload_mesh(bad, np.arange(6, dtype=np.uint32))
+        assert e.value.status == 1
     with pytest.raises(rr.RRError):
         r.set_tile_partition(2, 2)
     with pytest.raises(rr.RRError):

@@ -101,6 +101,31 @@ def test_mesh_load_edge_cases(tmp_path):
 
 
 # ---------------------------------------------------------------------------------- camera
+def test_position_validation(tmp_path):
+    """what rr_upload_mesh demands of positions (finite, |coordinate| <= 1e18), checked on the CPU; Mesh::load itself keeps
+    accepting such a file, as the reference's loader does (strtof("1e39") is +inf)"""
+    L = rr.lib()
+    bad = C.c_uint32(99)
+    v = np.zeros(5, rr.VERTEX_DTYPE)
+    v["position"] = np.arange(15, dtype=np.float32).reshape(5, 3)
+    assert L.rr_host_validate_positions(v.ctypes.data, 5, C.byref(bad)) == 0 and bad.value == 99
+    for val in (np.inf, -np.inf, np.nan, 1.1e18, -3e38):
+        w = v.copy()
+        w["position"][3, 1] = val
+        assert L.rr_host_validate_positions(w.ctypes.data, 5, C.byref(bad)) == 1 and bad.value == 3, val
+    w = v.copy()
+    w["position"][0] = (1e18, -1e18, 0)
+    assert L.rr_host_validate_positions(w.ctypes.data, 5, None) == 0
+    w["norm"][2] = np.nan                                        # normals and uvs are not positions
+    assert L.rr_host_validate_positions(w.ctypes.data, 5, None) == 0
+    assert L.rr_host_validate_positions(None, 0, None) == 0
+    p = tmp_path / "huge.obj"
+    p.write_text("v 1e39 0 0\nv 0 1 0\nv 0 0 1\nvt 0 0\nvn 0 0 1\nf 1/1/1 2/1/1 3/1/1\n")
+    m = rr.Mesh()
+    assert m.load(p) and np.isinf(np.asarray(m.verts)["position"][0, 0])
+    assert L.rr_host_validate_positions(np.asarray(m.verts).ctypes.data, 3, C.byref(bad)) == 1 and bad.value == 0
+
+
 def test_camera_matches_oracle_and_kats():
     for a in (0.01, 0.02, 1.0, 3.14, 6.28, -0.5):
         sc = rr.camera_orbit(a)
@@ -117,11 +142,17 @@ def test_camera_matches_oracle_and_kats():
 
 
 # ---------------------------------------------------------------------------------- stbi_loadf stand-in
+REF_STB = os.path.join(ROOT, "oracle", "_ref", "libstb_ref.so")
+
+
+def have_ref_stb():
+    """the reference's stb_image.h compiled in place (oracle/Makefile); only looked for here -- it is loaded by the two tests
+    that check against it, when they run, never at collection time (a `-m gpu` run does not map it)"""
+    return os.path.exists(REF_STB)
+
+
 def ref_stb():
-    path = os.path.join(ROOT, "oracle", "_ref", "libstb_ref.so")
-    if not os.path.exists(path):
-        return None
-    L = C.CDLL(path)
+    L = C.CDLL(REF_STB)
     L.stbi_loadf.restype = C.POINTER(C.c_float)
     L.stbi_loadf.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
     L.stbi_image_free.argtypes = [C.c_void_p]
@@ -153,7 +184,7 @@ def _write_png(path, arr, mode):
     Image.fromarray(arr, mode).save(path)
 
 
-@pytest.mark.skipif(ref_stb() is None, reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.skipif(not have_ref_stb(), reason="oracle/_ref not built (needs /root/reference)")
 @pytest.mark.parametrize("req", [0, 1, 2, 3, 4])
 def test_png_decode_bit_exact_vs_reference_stb(tmp_path, req):
     rng = np.random.default_rng(req)
@@ -206,7 +237,7 @@ def test_hdr_write_read_roundtrip(tmp_path):
     assert np.array_equal(again, back)
 
 
-@pytest.mark.skipif(ref_stb() is None, reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.skipif(not have_ref_stb(), reason="oracle/_ref not built (needs /root/reference)")
 @pytest.mark.parametrize("req", [0, 1, 3, 4])
 def test_hdr_decode_bit_exact_vs_reference_stb(tmp_path, req):
     from conftest import procedural_env

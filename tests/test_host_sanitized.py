@@ -11,7 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "refraction_raytracing_dxr_amd", "csrc", "host")
-ASSETS = os.path.join(ROOT, "tests", "golden", "assets")
+ASSETS = os.path.join(ROOT, "refraction_raytracing_dxr_amd", "assets")
 
 
 @pytest.fixture(scope="module")
