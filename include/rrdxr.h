@@ -240,6 +240,27 @@ int  rr_render_orbit_sharded_lane(rr_context* ctx, uint32_t width, uint32_t heig
                                   float fov_y, float aspect, float zn, float zf,
                                   void* d_tiles, uint64_t frame_stride_bytes, uint32_t lane);
 int  rr_lane_join(rr_context* ctx, uint32_t lane);
+/* ---- the final image gather, natively (north star: "host stays C++ ... final RCCL gather over xGMI") --------------------
+ * The reference has one adapter and no collective (RefractionDemo.cpp:163 NodeMask 0); here every rank renders its
+ * tiles and ONE gather per batch of frames brings them to the root.  RCCL is looked up at run time (dlopen of
+ * librccl.so; nothing links against it), one process per GPU:
+ *   rr_comm_unique_id   rank 0 makes the 128-byte id and hands it to the other processes (file, pipe, MPI ...)
+ *   rr_comm_init        ncclCommInitRank on the context's device; *comm is the communicator (opaque)
+ *   rr_gather_frames    every rank contributes bytes_per_rank bytes at d_send; the root receives rank r's block at
+ *                       d_recv + r * bytes_per_rank (d_recv may be NULL elsewhere).  Grouped ncclSend / ncclRecv, so the
+ *                       root's seven incoming transfers use its seven xGMI links side by side; enqueued on the context's
+ *                       stream (ordered after the renders before it, before the rr_assemble_frames after it).
+ *   rr_comm_destroy
+ * rr_device_alloc / rr_device_free / rr_device_read give a host without HIP headers the buffers these calls work on. */
+int  rr_comm_unique_id(void* id128);
+int  rr_comm_init(rr_context* ctx, const void* id128, int rank, int world, void** comm);
+int  rr_comm_destroy(void* comm);
+int  rr_gather_frames(rr_context* ctx, void* comm, int rank, int world, const void* d_send, void* d_recv,
+                      uint64_t bytes_per_rank, int root);
+int  rr_device_alloc(rr_context* ctx, uint64_t bytes, void** d_ptr);
+int  rr_device_free(rr_context* ctx, void* d_ptr);
+int  rr_device_read(rr_context* ctx, const void* d_src, void* host_dst, uint64_t bytes);   /* blocking */
+
 /* rank 0, after gathering n_frames at once: frame f of rank r lies at
  * d_gathered + r*rank_stride_bytes + f*frame_stride_bytes; writes n_frames W*H RGBA8 rasters to
  * d_frames + f*out_stride_bytes.  One launch for all frames. */

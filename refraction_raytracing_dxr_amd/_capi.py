@@ -106,6 +106,13 @@ SYMBOLS = {
     "rr_kernel_time": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "rr_trace_rays": (C.c_int, [_P, _P, C.c_uint32, _P]),
     "rr_env_lookup": (C.c_int, [_P, _P, C.c_uint32, _P]),
+    "rr_comm_unique_id": (C.c_int, [_P]),
+    "rr_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "rr_comm_destroy": (C.c_int, [_P]),
+    "rr_gather_frames": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, C.c_uint64, C.c_int]),
+    "rr_device_alloc": (C.c_int, [_P, C.c_uint64, C.POINTER(_P)]),
+    "rr_device_free": (C.c_int, [_P, _P]),
+    "rr_device_read": (C.c_int, [_P, _P, _P, C.c_uint64]),
     "rr_download_blas": (C.c_int, [_P, C.c_uint32, _P, C.POINTER(C.c_uint32), _P, C.POINTER(C.c_uint32)]),
     "rr_host_register": (C.c_int, [_P, _P, C.c_size_t]),
     "rr_host_unregister": (C.c_int, [_P, _P]),

@@ -14,6 +14,8 @@ float g_angle = 0.01f;                       // static float angle (RefractionDe
 std::vector<uint8_t> g_back;
 bool g_back_pinned = false;
 std::string g_err;
+void* g_comm = nullptr;                      // RCCL communicator of the sharded form
+int g_rank = 0, g_world = 1;
 
 int fail(int code, const char* what)
 {
@@ -106,6 +108,60 @@ int stream(int n_frames, int frames_per_dispatch, int in_flight, uint8_t* frames
     return RR_OK;
 }
 
+int initializeSharded(const Options& opt, int rank, int world, const void* id128)
+{
+    int rc = initialize(opt);
+    if (rc != RR_OK) return rc;
+    if ((rc = rr_set_tile_partition(g_ctx, (uint32_t)rank, (uint32_t)world)) != RR_OK) return fail(rc, "rr_set_tile_partition");
+    if ((rc = rr_comm_init(g_ctx, id128, rank, world, &g_comm)) != RR_OK) return fail(rc, "rr_comm_init");
+    g_rank = rank; g_world = world;
+    return RR_OK;
+}
+
+int pumpSharded(int n_frames, int frames_per_gather, rr_stats* stats)
+{
+    if (!g_ctx || !g_comm) return fail(RR_ERR_STATE, "initializeSharded first");
+    if (n_frames <= 0 || frames_per_gather <= 0) return fail(RR_ERR_INVALID_ARGUMENT, "pumpSharded: frame counts must be positive");
+    const uint32_t W = (uint32_t)g_opt.width, H = (uint32_t)g_opt.height;
+    uint32_t n_local = 0, max_tiles = 0;
+    int rc = rr_local_tile_count(g_ctx, W, H, &n_local, &max_tiles);
+    if (rc != RR_OK) return fail(rc, "rr_local_tile_count");
+    const uint64_t frame_stride = (uint64_t)max_tiles * 32 * 32 * 4;              // one rank's tiles of one frame, RGBA8
+    const uint64_t batch_bytes = frame_stride * (uint64_t)frames_per_gather;      // what every rank contributes per gather
+    const uint64_t raster = (uint64_t)W * H * 4;
+    void *d_send = nullptr, *d_recv = nullptr, *d_frames = nullptr;
+    if ((rc = rr_device_alloc(g_ctx, batch_bytes, &d_send)) != RR_OK) return fail(rc, "rr_device_alloc");
+    if (g_rank == 0) {
+        rc = rr_device_alloc(g_ctx, batch_bytes * (uint64_t)g_world, &d_recv);
+        if (rc == RR_OK) rc = rr_device_alloc(g_ctx, raster * (uint64_t)frames_per_gather, &d_frames);
+        if (rc != RR_OK) { rr_device_free(g_ctx, d_send); rr_device_free(g_ctx, d_recv); return fail(rc, "rr_device_alloc"); }
+    }
+    rr_dispatch_params p = g_opt.dispatch;
+    int last_n = 0;
+    for (int k = 0; k < n_frames && rc == RR_OK; k += frames_per_gather) {
+        const int n = n_frames - k < frames_per_gather ? n_frames - k : frames_per_gather;
+        if (k > 0) p.flags |= RR_DISPATCH_KEEP_COUNTERS;
+        rc = rr_render_orbit_sharded(g_ctx, W, H, &p, &g_angle, g_opt.angle_step, (uint32_t)n, (uint32_t)n, g_opt.fov_y, g_opt.aspect,
+                                     g_opt.zn, g_opt.zf, d_send, frame_stride);
+        if (rc != RR_OK) { fail(rc, "rr_render_orbit_sharded"); break; }
+        rc = rr_gather_frames(g_ctx, g_comm, g_rank, g_world, d_send, d_recv, batch_bytes, 0);
+        if (rc != RR_OK) { fail(rc, "rr_gather_frames"); break; }
+        if (g_rank == 0) {
+            rc = rr_assemble_frames(g_ctx, d_recv, (uint32_t)g_world, batch_bytes, frame_stride, (uint32_t)n, W, H, d_frames, raster);
+            if (rc != RR_OK) { fail(rc, "rr_assemble_frames"); break; }
+        }
+        last_n = n;
+    }
+    if (rc == RR_OK && g_rank == 0 && last_n > 0) {
+        rc = rr_device_read(g_ctx, (const uint8_t*)d_frames + (uint64_t)(last_n - 1) * raster, g_back.data(), raster);
+        if (rc != RR_OK) fail(rc, "rr_device_read");
+    }
+    if (rc == RR_OK) { rc = rr_wait(g_ctx); if (rc != RR_OK) fail(rc, "rr_wait"); }
+    if (rc == RR_OK && stats && (rc = rr_get_stats(g_ctx, stats)) != RR_OK) fail(rc, "rr_get_stats");
+    rr_device_free(g_ctx, d_send); rr_device_free(g_ctx, d_recv); rr_device_free(g_ctx, d_frames);
+    return rc;
+}
+
 const std::vector<uint8_t>& backBuffer() { return g_back; }
 rr_context* context() { return g_ctx; }
 float currentAngle() { return g_angle; }
@@ -113,6 +169,7 @@ const char* lastError() { return g_err.c_str(); }
 
 void shutdown()
 {
+    if (g_comm) { rr_comm_destroy(g_comm); g_comm = nullptr; }
     if (g_ctx) {
         if (g_back_pinned) { rr_host_unregister(g_ctx, g_back.data()); g_back_pinned = false; }
         rr_destroy(g_ctx); g_ctx = nullptr;

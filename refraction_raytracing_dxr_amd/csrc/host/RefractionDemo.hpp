@@ -31,6 +31,13 @@ int drawFrame();                          // RefractionDemo.cpp:557-612; returns
 int pump(int n_frames, int frames_per_dispatch, int in_flight, rr_stats* stats);
 // the frame loop with every frame copied to host memory while the next ones render; frames: n_frames*w*h*4 bytes
 int stream(int n_frames, int frames_per_dispatch, int in_flight, uint8_t* frames);
+// Several GPUs, one process each (rank of world): frames shard by 32x32 tile, tile t to rank t % world; every rank renders
+// its tiles of a batch of frames, ONE grouped RCCL gather brings them to rank 0, which de-interleaves them into whole frames.
+// id128: the 128 bytes rank 0 got from rr_comm_unique_id, handed to every process.  The reference has a single adapter
+// (RefractionDemo.cpp:163); this is the tile-parallel form of its frame loop.
+int initializeSharded(const Options& opt, int rank, int world, const void* id128);
+// n_frames of the orbit in batches of frames_per_gather; on rank 0 the last frame lands in backBuffer()
+int pumpSharded(int n_frames, int frames_per_gather, rr_stats* stats);
 // the frame drawFrame just produced (RGBA8, width*height*4), i.e. what Present would have shown
 const std::vector<uint8_t>& backBuffer();
 rr_context* context();

@@ -30,6 +30,7 @@ static_assert(sizeof(rr_ray) == sizeof(rr_ray_dev) && sizeof(rr_hit) == sizeof(r
 // Optional roctx ranges around the coarse steps (build, dispatch, assemble) so that `rocprofv3 --marker-trace`
 // shows them next to the kernels.  The marker library is looked up at run time; without it the calls are no-ops.
 #include <dlfcn.h>
+#include <rccl/rccl.h>      // types only (ncclUniqueId, ncclUint8): the library is looked up with dlopen, nothing links against it
 namespace {
 struct Roctx {
     int (*push)(const char*) = nullptr;
@@ -1302,6 +1303,112 @@ int rr_assemble_frames_rgb8(rr_context* ctx, const void* d_gathered, uint32_t wo
         return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_assemble_frames_rgb8: stride too small");
     RR_HIP(launch_assemble_frames_rgb8((const uint8_t*)d_gathered, (uint32_t*)d_frames, width, height, tx, nt, world,
                                        rank_stride_bytes, frame_stride_bytes, out_stride_bytes / 4, n_frames, ctx->stream));
+    return RR_OK;
+}
+
+// ---- RCCL, looked up at run time ---------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, ncclUniqueId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    Rccl()
+    {
+        // a process that already holds an RCCL (PyTorch's) must use that one: two copies of its globals do not mix
+        const char* names[] = { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so" };
+        for (const char* n : names) if (!lib) lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        for (const char* n : names) if (!lib) lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!lib) return;
+        GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
+        CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
+        Send = (decltype(Send))dlsym(lib, "ncclSend");
+        Recv = (decltype(Recv))dlsym(lib, "ncclRecv");
+        GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        ok = GetUniqueId && CommInitRank && CommDestroy && GroupStart && GroupEnd && Send && Recv;
+    }
+};
+const Rccl& rccl() { static const Rccl r; return r; }
+static_assert(sizeof(ncclUniqueId) == 128, "rr_comm_unique_id hands out 128 bytes");
+} // namespace
+
+int rr_comm_unique_id(void* id128)
+{
+    if (!id128) return RR_ERR_INVALID_ARGUMENT;
+    if (!rccl().ok) return RR_ERR_UNSUPPORTED;                    // no librccl.so on this machine
+    return rccl().GetUniqueId(id128) == 0 ? RR_OK : RR_ERR_DEVICE;
+}
+
+int rr_comm_init(rr_context* ctx, const void* id128, int rank, int world, void** comm)
+{
+    if (int r = use_device(ctx)) return r;                        // the communicator belongs to the context's device
+    if (!id128 || !comm || world < 1 || rank < 0 || rank >= world) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_comm_init: bad arguments");
+    if (!rccl().ok) return fail(ctx, RR_ERR_UNSUPPORTED, "rr_comm_init: librccl.so not found");
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    *comm = nullptr;
+    const int e = rccl().CommInitRank(comm, world, id, rank);
+    if (e != 0) { ctx->err = std::string("ncclCommInitRank: ") + (rccl().GetErrorString ? rccl().GetErrorString(e) : "error"); return RR_ERR_DEVICE; }
+    return RR_OK;
+}
+
+int rr_comm_destroy(void* comm)
+{
+    if (!comm) return RR_OK;
+    if (!rccl().ok) return RR_ERR_UNSUPPORTED;
+    return rccl().CommDestroy(comm) == 0 ? RR_OK : RR_ERR_DEVICE;
+}
+
+int rr_gather_frames(rr_context* ctx, void* comm, int rank, int world, const void* d_send, void* d_recv, uint64_t bytes_per_rank, int root)
+{
+    const Range range_("rr_gather_frames");
+    if (int r = use_device(ctx)) return r;
+    if (!comm || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world || !d_send || (rank == root && !d_recv))
+        return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_gather_frames: bad arguments");
+    if (!rccl().ok) return fail(ctx, RR_ERR_UNSUPPORTED, "rr_gather_frames: librccl.so not found");
+    if (bytes_per_rank == 0) return RR_OK;
+    const Rccl& R = rccl();
+    int e = R.GroupStart();
+    if (e == 0) e = R.Send(d_send, (size_t)bytes_per_rank, (int)ncclUint8, root, comm, ctx->stream);
+    if (rank == root)
+        for (int r = 0; r < world && e == 0; ++r)
+            e = R.Recv((char*)d_recv + (size_t)r * bytes_per_rank, (size_t)bytes_per_rank, (int)ncclUint8, r, comm, ctx->stream);
+    const int e2 = R.GroupEnd();
+    if (e == 0) e = e2;
+    if (e != 0) { ctx->err = std::string("rr_gather_frames: ") + (R.GetErrorString ? R.GetErrorString(e) : "RCCL error"); return RR_ERR_DEVICE; }
+    return RR_OK;
+}
+
+int rr_device_alloc(rr_context* ctx, uint64_t bytes, void** d_ptr)
+{
+    if (int r = use_device(ctx)) return r;
+    if (!d_ptr || bytes == 0) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_device_alloc: bad arguments");
+    RR_HIP(hipMalloc(d_ptr, (size_t)bytes));
+    return RR_OK;
+}
+
+int rr_device_free(rr_context* ctx, void* d_ptr)
+{
+    if (int r = use_device(ctx)) return r;
+    if (d_ptr) { RR_HIP(hipStreamSynchronize(ctx->stream)); RR_HIP(hipFree(d_ptr)); }
+    return RR_OK;
+}
+
+int rr_device_read(rr_context* ctx, const void* d_src, void* host_dst, uint64_t bytes)
+{
+    if (int r = use_device(ctx)) return r;
+    if (!d_src || !host_dst) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_device_read: null pointer");
+    RR_HIP(hipMemcpyAsync(host_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RR_HIP(hipStreamSynchronize(ctx->stream));
     return RR_OK;
 }
 

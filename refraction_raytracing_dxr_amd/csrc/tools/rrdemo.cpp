@@ -3,6 +3,7 @@
 //   rrdemo --mesh shell.obj --env envmap.png [--size 1024x768] [--frames 10] [--out frame_%03d.ppm]
 //          [--pump] [--frames-per-dispatch F] [--in-flight L]     (--pump: the loop without per-frame read-back)
 //          [--stream]                                              (every frame to host memory, copies overlap rendering)
+//          [--gpus N [--frames-per-gather F]]                      (one process per GPU: tiles, one RCCL gather per F frames)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -10,14 +11,49 @@
 #include <string>
 #include <vector>
 
+#include <spawn.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include "../host/RefractionDemo.hpp"
+
+extern char** environ;
+
+// --gpus N: this process only starts N copies of itself (ranks 0..N-1, device = --device + rank) and waits for them; it never
+// touches a GPU.  Rank 0 makes the RCCL id and leaves it in a file the others wait for.
+static int launch_ranks(int argc, char** argv, int gpus)
+{
+    char idfile[256];
+    snprintf(idfile, sizeof idfile, "/tmp/rrdemo_id_%d", (int)getpid());
+    unlink(idfile);
+    std::vector<pid_t> pids;
+    for (int r = 0; r < gpus; ++r) {
+        std::vector<std::string> a(argv, argv + argc);
+        a.push_back("--rank"); a.push_back(std::to_string(r));
+        a.push_back("--id-file"); a.push_back(idfile);
+        std::vector<char*> av;
+        for (auto& x : a) av.push_back(const_cast<char*>(x.c_str()));
+        av.push_back(nullptr);
+        pid_t pid;
+        if (posix_spawn(&pid, "/proc/self/exe", nullptr, nullptr, av.data(), environ) != 0) { fprintf(stderr, "cannot start rank %d\n", r); break; }
+        pids.push_back(pid);
+    }
+    int worst = (int)pids.size() == gpus ? 0 : 1;
+    for (pid_t pid : pids) {
+        int st = 0;
+        if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) worst = 1;
+    }
+    unlink(idfile);
+    return worst;
+}
 
 int main(int argc, char** argv)
 {
     RefractionDemo::Options opt;
-    int frames = 1, fpd = 1, in_flight = 2;
+    int frames = 1, fpd = 1, in_flight = 2, gpus = 0, rank = -1, fpg = 16;
     bool pump = false, stream = false;
-    std::string out;
+    std::string out, idfile;
     for (int i = 1; i < argc; ++i) {
         auto arg = [&](const char* name) { return !strcmp(argv[i], name) && i + 1 < argc; };
         if (arg("--mesh")) opt.mesh_path = argv[++i];
@@ -29,10 +65,52 @@ int main(int argc, char** argv)
         else if (arg("--frames-per-dispatch")) fpd = atoi(argv[++i]);
         else if (arg("--in-flight")) in_flight = atoi(argv[++i]);
         else if (arg("--device")) opt.device = atoi(argv[++i]);
+        else if (arg("--gpus")) gpus = atoi(argv[++i]);
+        else if (arg("--frames-per-gather")) fpg = atoi(argv[++i]);
+        else if (arg("--rank")) rank = atoi(argv[++i]);
+        else if (arg("--id-file")) idfile = argv[++i];
         else if (arg("--max-refract")) opt.dispatch.max_refract = atoi(argv[++i]);
         else if (arg("--max-reflect")) opt.dispatch.max_reflect = atoi(argv[++i]);
         else if (arg("--size")) { if (sscanf(argv[++i], "%dx%d", &opt.width, &opt.height) != 2) { fprintf(stderr, "bad --size\n"); return 2; } }
         else { fprintf(stderr, "usage: rrdemo --mesh M.obj --env E.(hdr|png) [--size WxH] [--frames N] [--out f_%%03d.ppm]\n"); return 2; }
+    }
+    if (gpus > 0 && rank < 0) return launch_ranks(argc, argv, gpus);
+    if (gpus > 0) {         // one rank of a sharded run
+        unsigned char id[128];
+        const std::string tmp = idfile + ".tmp";
+        if (rank == 0) {
+            if (rr_comm_unique_id(id) != RR_OK) { fprintf(stderr, "rr_comm_unique_id failed (is librccl.so installed?)\n"); return 1; }
+            FILE* f = fopen(tmp.c_str(), "wb");
+            if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) { fprintf(stderr, "cannot write %s\n", tmp.c_str()); return 1; }
+            fclose(f);
+            rename(tmp.c_str(), idfile.c_str());
+        } else {
+            FILE* f = nullptr;
+            for (int tries = 0; tries < 6000 && !(f = fopen(idfile.c_str(), "rb")); ++tries) usleep(10000);
+            if (!f || fread(id, 1, sizeof id, f) != sizeof id) { fprintf(stderr, "rank %d: no RCCL id from rank 0\n", rank); return 1; }
+            fclose(f);
+        }
+        opt.device += rank;
+        int rc = RefractionDemo::initializeSharded(opt, rank, gpus, id);
+        if (rc != RR_OK) { fprintf(stderr, "rank %d: initialize failed (%d): %s\n", rank, rc, RefractionDemo::lastError()); return 1; }
+        auto t0 = std::chrono::steady_clock::now();
+        rr_stats st;
+        if ((rc = RefractionDemo::pumpSharded(frames, fpg, &st)) != RR_OK) { fprintf(stderr, "rank %d: pump failed (%d): %s\n", rank, rc, RefractionDemo::lastError()); return 1; }
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("rank %d of %d: %d frames of %dx%d in %.3f s (%.1f fps; %.1f Mrays/s on this rank; %d frames per gather)\n", rank, gpus, frames,
+               opt.width, opt.height, s, frames / s, (double)st.rays / s / 1e6, fpg);
+        if (rank == 0 && !out.empty()) {
+            char name[1024];
+            snprintf(name, sizeof name, out.c_str(), frames - 1);
+            FILE* f = fopen(name, "wb");
+            if (!f) { fprintf(stderr, "cannot write %s\n", name); return 1; }
+            fprintf(f, "P6\n%d %d\n255\n", opt.width, opt.height);
+            const auto& bb = RefractionDemo::backBuffer();
+            for (size_t p = 0; p < (size_t)opt.width * opt.height; ++p) fwrite(&bb[p * 4], 1, 3, f);
+            fclose(f);
+        }
+        RefractionDemo::shutdown();
+        return 0;
     }
     int rc = RefractionDemo::initialize(opt);
     if (rc != RR_OK) { fprintf(stderr, "initialize failed (%d): %s\n", rc, RefractionDemo::lastError()); return 1; }

@@ -8,6 +8,7 @@ Bars (stated once, used below):
   * frame, RGBA8: <= 1 LSB per channel against the literal oracle, identical against path-weight.
   * exact counters (rays, hits, misses, terminal hits, TIR) equal the oracle's.
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -1039,6 +1040,37 @@ def test_full_size_config5_properties(gpu):
     assert np.array_equal(a[y0:y0 + 32, x0:x0 + 48], ref["rgba8"][y0:y0 + 32, x0:x0 + 48])
 
 
+def test_full_size_config4_properties(gpu):
+    """C4 at full size (shell + cube + ott, three BLASes under one TLAS, 3840x2160, 8 bounces; placement as in
+    tools/exp_configs.py and bench.py): runs, no stack overflow, deterministic, counters consistent, the same frame from a
+    16-slice DispatchRays and from a single one; windows on each of the three meshes are checked against the oracle."""
+    meshes = [load("shell.obj"), load("cube.obj"), load("ott.obj")]
+    env = procedural_env(512, 256, seed=7)
+    inst = rr.make_instances(transforms=[_xf(0, 0, 0), _xf(0, 0, -4.0), _xf(0, 0, 4.0)], meshes=[0, 1, 2])
+    gpu_scene(gpu, meshes, env, inst)
+    sc = rr.camera_orbit(0.01)
+    for k in (0, 2):
+        sc.camera_loc[k] *= 1.6
+    W, H = 3840, 2160
+    gpu.set_tile_partition(0, 1)
+    gpu.set_camera(sc)
+    gpu.dispatch_rays(W, H, rr.default_params(max_refract=8, flags=rr.DISPATCH_COLLECT_STATS))
+    a = gpu.read_frame().copy()
+    st = gpu.stats()
+    assert st.traversal_overflow == 0 and st.pixels == W * H and st.hits + st.misses == st.rays and st.rays > 2 * W * H
+    gpu.dispatch_rays(W, H, rr.default_params(max_refract=8))
+    assert np.array_equal(gpu.read_frame(), a)
+    gpu.dispatch_rays_batch(W, H, [sc] * 3, rr.default_params(max_refract=8))             # the batched launch shape
+    assert np.array_equal(gpu.read_frame(slice=2), a)
+    s = oracle_scene(meshes, env, inst)
+    M, cam = np.array(sc.proj_inv, np.float32), np.array(sc.camera_loc, np.float32)
+    covered = a[..., :3].astype(int).sum(axis=2)
+    for x0, y0 in ((1900, 1060), (700, 1060), (3000, 1000)):                             # shell, one side mesh, the other
+        ref = s.render(M, cam, W, H, O.default_params(use_bvh=1, max_refract=8, accum_mode=1), region=(x0, y0, x0 + 40, y0 + 24))
+        assert np.array_equal(a[y0:y0 + 24, x0:x0 + 40], ref["rgba8"][y0:y0 + 24, x0:x0 + 40]), (x0, y0)
+        assert ref["stats"].rays >= 40 * 24
+
+
 def test_rrdemo_cli(tmp_path, env_png):
     """the headless WinMain replacement: C++ host (Mesh, RefractionDemo::initialize/drawFrame) end to end"""
     import subprocess
@@ -1076,6 +1108,47 @@ def test_rrdemo_cli(tmp_path, env_png):
         assert open(tmp_path / ("t_%03d.ppm" % k), "rb").read() == open(tmp_path / ("s_%03d.ppm" % k), "rb").read()
     bad = subprocess.run([exe, "--mesh", str(tmp_path / "missing.obj"), "--env", str(hdr)], capture_output=True, text=True)
     assert bad.returncode == 1 and "mesh could not be loaded" in bad.stderr
+    # the sharded C++ host, one process per GPU (here: one): tiles -> rr_gather_frames (RCCL, grouped send/recv) ->
+    # rr_assemble_frames; the launcher process itself never touches the GPU.  Same seventh frame as drawFrame's.
+    sh = subprocess.run([exe, "--mesh", O.asset("shell.obj"), "--env", str(hdr), "--size", "256x192", "--frames", "7", "--gpus", "1",
+                         "--frames-per-gather", "3", "--out", str(tmp_path / "g_%03d.ppm")], capture_output=True, text=True, timeout=300)
+    assert sh.returncode == 0 and "rank 0 of 1: 7 frames of 256x192" in sh.stdout, sh.stderr + sh.stdout
+    assert open(tmp_path / "g_006.ppm", "rb").read() == open(tmp_path / "s_006.ppm", "rb").read()
+
+
+def test_native_rccl_gather_entry_points(gpu):
+    """rr_comm_* / rr_gather_frames / rr_device_* through the C ABI with a communicator of one rank: the tiles of three
+    frames are gathered (a grouped ncclSend + ncclRecv to itself), de-interleaved by rr_assemble_frames and read back --
+    byte for byte the frames of an unsharded dispatch.  (More ranks need more GPUs: the driver's 8-GPU run.)"""
+    L = rr.lib()
+    m = load("monkey.obj")
+    gpu_scene(gpu, [m], procedural_env(64, 32, seed=3))
+    W, H, F = 200, 120, 3
+    p = rr.default_params(max_refract=4)
+    gpu.set_tile_partition(0, 1)
+    gpu.render_orbit(W, H, F, angle=0.2, params=p, frames_per_dispatch=F)
+    want = [gpu.read_frame(slice=k).copy() for k in range(F)]
+    ident = (C.c_ubyte * 128)()
+    assert L.rr_comm_unique_id(ident) == 0
+    comm = C.c_void_p()
+    gpu._ck(L.rr_comm_init(gpu._h, ident, 0, 1, C.byref(comm)), "rr_comm_init")
+    n_local, max_tiles = gpu.local_tile_count(W, H)
+    stride = max_tiles * 32 * 32 * 4
+    d_send, d_recv, d_frames = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    for ptr, nbytes in ((d_send, F * stride), (d_recv, F * stride), (d_frames, F * W * H * 4)):
+        gpu._ck(L.rr_device_alloc(gpu._h, nbytes, C.byref(ptr)), "rr_device_alloc")
+    gpu.render_orbit_sharded(W, H, F, d_send.value, stride, angle=0.2, params=p, frames_per_dispatch=F)
+    gpu._ck(L.rr_gather_frames(gpu._h, comm, 0, 1, d_send, d_recv, F * stride, 0), "rr_gather_frames")
+    gpu.assemble_frames(d_recv.value, 1, F * stride, stride, F, W, H, d_frames.value, W * H * 4)
+    got = np.empty((F, H, W, 4), np.uint8)
+    gpu._ck(L.rr_device_read(gpu._h, d_frames, got.ctypes.data, got.nbytes), "rr_device_read")
+    for k in range(F):
+        assert np.array_equal(got[k], want[k]), k
+    with pytest.raises(rr.RRError):
+        gpu._ck(L.rr_gather_frames(gpu._h, comm, 1, 1, d_send, d_recv, 16, 0), "rr_gather_frames")      # rank >= world
+    for ptr in (d_send, d_recv, d_frames):
+        gpu._ck(L.rr_device_free(gpu._h, ptr), "rr_device_free")
+    assert L.rr_comm_destroy(comm) == 0
 
 
 # ------------------------------------------------------------------------------- large mesh (builder at scale)
