@@ -249,6 +249,21 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         region_ms = None
+        # attribution of the N-GPU figure (untimed extra): every rank's share of the same frames rendered without the gather
+        # and the de-interleave -- if the end-to-end time is far above the slowest rank's render time, the rest is rank 0's
+        # ingest (7/8 of every frame crosses xGMI into one GPU) and its assemble launches, not the render kernel
+        barrier()
+        t1 = time.perf_counter()
+        sf.render_only(K, angle=0.01, params=params)
+        torch.cuda.synchronize()
+        render_only = time.perf_counter() - t1
+        ro = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)] if dist.get_world_size() > 1 else None
+        mine = torch.tensor([render_only], dtype=torch.float64, device="cuda")
+        if ro is not None:
+            dist.all_gather(ro, mine)
+            render_only_all = [float(x[0]) for x in ro]
+        else:
+            render_only_all = [render_only]
         t = torch.tensor([elapsed, float(rays_local), float(r.stats().traversal_overflow)], dtype=torch.float64, device="cuda")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -376,6 +391,12 @@ def main():
                        "launch_shape": "DispatchRays(W, H, Depth = frames_per_dispatch): every frame complete in its own buffer; the "
                                        "reference's own shape, Depth 1, is roofline.depth1_kernel_us"},
             "device_region_ms_per_step": round(region_ms / K, 5) if region_ms is not None else None,
+            "multi_gpu_attribution": None if world == 1 and not force_sharded else {
+                "end_to_end_ms_per_step": round(elapsed / K * 1e3, 5),
+                "render_only_ms_per_step_by_rank": [round(x / K * 1e3, 5) for x in render_only_all],
+                "note": "render_only: each rank's tiles of the same frames, same launches and lanes, no gather, no de-interleave "
+                        "(untimed extra pass).  end_to_end - max(render_only) = rank 0's gather ingest + assemble that the pipeline "
+                        "did not hide"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "monkey_16k": subdiv,

@@ -199,6 +199,30 @@ class ShardedFrames:
             self._finish(gathering)
         return self.r.stats().rays
 
+    def render_only(self, n_frames, angle=0.01, angle_step=0.01, params=None):
+        """The render launches of render_orbit -- same batches, same two lanes, same tile buffers -- without the gather
+        and the de-interleave: what a rank's share of the frames costs by itself.  For attributing a scaling curve
+        (render / gather ingest / assemble); the tiles are rendered and thrown away."""
+        from .host import default_params
+        from ._capi import DISPATCH_KEEP_COUNTERS, DISPATCH_TILES_RGB8
+        base = params if params is not None else default_params()
+        done, b = 0, 0
+        while done < n_frames:
+            nf = min(self.F, n_frames - done)
+            slot, lane = b % self.RING, b % self.LANES
+            p = default_params()
+            for f, _ in base._fields_:
+                setattr(p, f, getattr(base, f))
+            p.flags |= DISPATCH_KEEP_COUNTERS | (DISPATCH_TILES_RGB8 if self.rgb8 else 0)
+            if b >= self.LANES:
+                self.r.lane_join((b - self.LANES) % self.LANES)
+            angle = self.r.render_orbit_sharded(self.width, self.height, nf, self.send[slot].data_ptr(), self.frame_bytes,
+                                                angle=angle, angle_step=angle_step, params=p, frames_per_dispatch=nf, lane=lane)
+            done += nf
+            b += 1
+        for lane in range(min(b, self.LANES)):
+            self.r.lane_join(lane)
+
     def _advance(self, rendered, gathering):
         """join + gather the batch that was launched before the newest one; finish the one before that"""
         slot, nf, lane, dst = rendered
