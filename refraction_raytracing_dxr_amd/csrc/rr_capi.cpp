@@ -157,6 +157,8 @@ struct rr_context {
     int  dbg_kernel = 0;             // RR_DEBUG_KERNEL: 0 default, 1 "fused" (never the LDS kernel), 2 "async", 3 "wavefront", 4 "lds" (at every depth)
     int  dbg_stack = 0;              // RR_DEBUG_STACK
     int  dbg_ticket_blocks = 0;      // RR_DEBUG_TICKET: 1 = k_render_lds treats the whole frame as the mesh rectangle, 2 = no rectangle
+    uint32_t dbg_async[2] = { 2, 2 };    // RR_DEBUG_ASYNC="leaf,shade": thresholds of k_render_scene_async in eighths (rr_types.h)
+    bool dbg_tlas32 = false;         // RR_DEBUG_TLAS32: two-level scenes keep 32-bit stack entries and register-parked rays
     int  dbg_shape = 0;              // RR_DEBUG_SHAPE: first k_render_lds workgroup shape to consider (rr_launch.h)
     std::string dbg_diag;            // RR_DEBUG_DIAG: file that receives per-wave diagnostics of Depth-1 dispatches
 
@@ -354,10 +356,12 @@ int rr_create(int device_ordinal, rr_context** out)
     (void)hipMemsetAsync(ctx->d_cnt, 0, sizeof(CounterBlock), ctx->stream);
     (void)hipMemsetAsync(ctx->d_tickets, 0, (rr_context::MAX_LANES + 1) * LDS_TICKET_WORDS * sizeof(uint32_t), ctx->stream);   // the kernel leaves them zero
     if (const char* e = getenv("RR_DEBUG_KERNEL"))
-        ctx->dbg_kernel = !strcmp(e, "fused") ? 1 : !strcmp(e, "async") ? 2 : !strcmp(e, "wavefront") ? 3 : !strcmp(e, "lds") ? 4 : !strcmp(e, "paths") ? 5 : !strcmp(e, "refill") ? 6 : 0;
+        ctx->dbg_kernel = !strcmp(e, "fused") ? 1 : !strcmp(e, "async") ? 2 : !strcmp(e, "wavefront") ? 3 : !strcmp(e, "lds") ? 4 : !strcmp(e, "paths") ? 5 : !strcmp(e, "refill") ? 6 : !strcmp(e, "scene-async") ? 8 : 0;
     if (const char* e = getenv("RR_DEBUG_STACK")) ctx->dbg_stack = atoi(e);
     if (const char* e = getenv("RR_DEBUG_TICKET")) ctx->dbg_ticket_blocks = atoi(e);
     if (const char* e = getenv("RR_DEBUG_SHAPE")) ctx->dbg_shape = atoi(e);
+    if (const char* e = getenv("RR_DEBUG_TLAS32")) ctx->dbg_tlas32 = atoi(e) != 0;
+    if (const char* e = getenv("RR_DEBUG_ASYNC")) { unsigned l = 2, sh = 2; if (sscanf(e, "%u,%u", &l, &sh) == 2 && l >= 1 && sh >= 1) { ctx->dbg_async[0] = l; ctx->dbg_async[1] = sh; } }
     if (const char* e = getenv("RR_DEBUG_DIAG")) ctx->dbg_diag = e;
     *out = ctx;
     return RR_OK;
@@ -811,6 +815,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     DispatchDev a;
     memset(&a, 0, sizeof a);
     a.sx = ctx->d_screen; a.sy = ctx->d_screen + width;
+    a.async_leaf_num = ctx->dbg_async[0]; a.async_shade_num = ctx->dbg_async[1];
     {   // where the scene can be seen at all in these slices
         uint32_t hr[4];
         mesh_screen_rect(ctx->scene_bounds, h_cams, depth, width, height, hr);
@@ -934,6 +939,8 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     }
     const bool refill_stack16 = ctx->single_identity ? (m0 && m0->n_tris < 32768u && need > 19)
                                                      : (pool_nodes < 32768u && ctx->n_pool_tris + ctx->n_insts < 32768u);
+    // (experiment, RR_DEBUG_KERNEL=scene-async: the lane-asynchronous kernel for scenes with a TLAS, see rr_render_exp.hip)
+    const bool scene_async = ctx->dbg_kernel == 8 && !ctx->single_identity && p.max_reflect <= 2 && need <= 39 && !a.diag && ctx->dbg_stack == 0 && !paths_kernel;
     // (experiment, RR_DEBUG_KERNEL=refill: on the 1 024-monkey grid it raises the share of live lanes per shading pass from
     // 54 % to 80 % and the frame time from 8.9 to 10.8 ms -- a pass lasts as long as its longest ray either way, and with
     // every lane alive that one is longer)
@@ -941,6 +948,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
 #ifdef RR_EXPERIMENTAL
     if (wavefront) RR_HIP(launch_render_wavefront(sc, a, ctx->wf, stack_sel, ctx->stream));
     else if (refill_kernel) RR_HIP(launch_render_refill(sc, a, (int)need, stats, ctx->stream, refill_stack16));
+    else if (scene_async) RR_HIP(launch_render_scene_async(sc, a, (int)need, stats, ctx->stream, refill_stack16));
     else if (ctx->dbg_kernel == 2 && ctx->single_identity) RR_HIP(launch_render_async(sc, a, stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream));
     else
 #endif
@@ -980,10 +988,12 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         // deep trees of small meshes: 16-bit stack entries keep eight waves per SIMD (LDS would otherwise allow 6/5/4)
         bool stack16 = ctx->single_identity && need > 19 && need <= 39 && ctx->dbg_stack == 0 &&
                        ctx->meshes[(size_t)ctx->inst_host[0].blas].n_tris < 32768u;
+        // two-level scenes: 16-bit entries wherever every node / leaf reference of the pool fits them (RR_DEBUG_TLAS32=1: never)
+        if (!ctx->single_identity && refill_stack16 && need <= 39 && ctx->dbg_stack == 0 && !ctx->dbg_tlas32) stack16 = true;
         // one or two slices per launch: the tail of a few long waves sets the time, and those run faster without the
         // spills of the 6..8-wave builds (monkey Depth 1: 446 us with the 5-wave build, 475 with the 8-wave one)
         if (depth <= 2 && ctx->single_identity && stack_sel < 31 && ctx->dbg_stack == 0) { stack_sel = 31; stack16 = false; }
-        if (depth <= 2) stack16 = false;
+        if (depth <= 2 && ctx->single_identity) stack16 = false;
         RR_HIP(launch_render_fused(sc, a, stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream, stack16));
     }
     if (tune_slot >= 0) {
@@ -1001,7 +1011,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         (void)hipFree(d_diag);
         if (FILE* f = fopen(diag_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
-    ctx->last_kernel = wavefront ? 3u : paths_kernel ? 2u : refill_kernel ? 4u : lds_kernel ? 1u : 0u;
+    ctx->last_kernel = wavefront ? 3u : paths_kernel ? 2u : refill_kernel ? 4u : scene_async ? 5u : lds_kernel ? 1u : 0u;
     ctx->W = width; ctx->H = height; ctx->frame_world = ctx->tile_world; ctx->frame_depth = depth;
     ctx->have_f32 = want_f32; ctx->have_frame = ext_tiles == nullptr; ctx->have_assembled = false;
     if (!ext_tiles) ctx->frame_base = out_base;

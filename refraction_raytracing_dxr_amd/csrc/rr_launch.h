@@ -50,6 +50,8 @@ hipError_t launch_render_wavefront(const SceneDev& sc, const DispatchDev& a, con
 hipError_t launch_render_async(const SceneDev& sc, const DispatchDev& a, int stack, int pend, bool stats, hipStream_t s);
 // pixel refill (k_render_refill): a wave's lanes take the next pixel of its 256-pixel column as theirs finish
 hipError_t launch_render_refill(const SceneDev& sc, const DispatchDev& a, int stack, bool stats, hipStream_t s, bool stack16);
+// scenes with a TLAS: lane-asynchronous renderer (k_render_scene_async)
+hipError_t launch_render_scene_async(const SceneDev& sc, const DispatchDev& a, int stack, bool stats, hipStream_t s, bool stack16);
 #endif
 
 // ---- rr_bvh_build.hip

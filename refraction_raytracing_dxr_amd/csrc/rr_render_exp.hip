@@ -527,4 +527,186 @@ hipError_t launch_render_wavefront(const SceneDev& sc, const DispatchDev& a, con
     return launch_wavefront_s<64>(sc, a, wf, s);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Lane-asynchronous renderer for scenes beyond the reference's single instance (a TLAS over many instances).  EXPERIMENT
+// (RR_DEBUG_KERNEL=scene-async): on the 1 024-monkey grid it cuts the internal-node trips from 63 M to 23 M per frame
+// (lane utilisation 17 % -> 45 %) and still takes 12.9 ms against k_render_fused's 8.9 -- a leaf step (triangle test,
+// instance entry and exit, each run in turn for the few lanes that need it) and a shading pass cost ten to twenty times an
+// internal-node step, and this form makes as many of them as the lock-step one (thresholds from 1/4 to 7/8 tried).
+// There the rays of a wave differ enormously in length -- on the 1 024-monkey grid a shading pass of k_render_fused lasts
+// 95 loop trips for rays that need 29 on average (a ray skimming the grid crosses dozens of instance boxes), and only 17 % of
+// the lanes of an internal-node step do anything.  Here every lane runs its own pixel as a little machine -- at an
+// internal node / holding a leaf or the end of a subtree / ray finished, to be shaded / without a pixel -- and the WAVE
+// picks, each trip, the one kind of step most of its lanes are waiting for: an internal-node step, a leaf step (triangle
+// test, instance entry or exit) or a shading pass (ClosestHit / Miss, next ray or next pixel of the wave's 256-pixel
+// column).  A lane never waits for another lane's ray.  Every lane still performs exactly the operations of
+// trace_scene<TLAS> and shade_ray for its own rays, in the same order, so frames and counters are bit-identical to
+// k_render_fused's.
+template <int STACK, bool STATS, class E, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_render_scene_async(SceneDev sc, DispatchDev a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    E* const stk = reinterpret_cast<E*>(lds) + wave * (STACK * 64) + lane;
+    LdsPark park{ lds + (4u * STACK * 64u * (uint32_t)sizeof(E)) / 4u + wave * (2u * 8u * 64u) + lane };
+
+    // workgroup = one 32x32 tile of one slice (slices interleaved); wave w = its 8-pixel-wide column w (256 pixels)
+    const uint32_t frame = blockIdx.x % a.n_frames;
+    const uint32_t tile_local = blockIdx.x / a.n_frames;
+    if (tile_local >= a.n_local_tiles) return;
+    const uint32_t tile = tile_local * a.tile_world + a.tile_rank;
+    const uint32_t x0 = (tile % a.tiles_x) * TILE + wave * 8u, y0 = (tile / a.tiles_x) * TILE;
+    const CamDev& cb = a.cams[frame];
+    uint32_t* const out_rgba8 = a.out_rgba8 + (size_t)frame * a.frame_stride;
+    float4* const out_f32 = a.out_f32 ? a.out_f32 + (size_t)frame * a.frame_stride : nullptr;
+    const bool col_may_hit = x0 + 8u > a.hx0 && x0 < a.hx1;
+
+    constexpr int TRAV_FIN = (int)0x80000001;       // the lane's ray is finished: shade it
+    constexpr uint32_t NO_INST = 0xffffffffu;
+    constexpr uint32_t TOTAL = 4u * 64u;            // pixels of the column
+    const QNode* __restrict__ nodes = sc.pool_nodes;
+
+    LaneStats st;
+    st.blocks = 4u;
+    uint32_t cursor = 0;                            // next pixel of the column to hand out (wave-uniform)
+    bool alive = false;
+    uint32_t pix = 0;
+    RayState r;
+    r.O = r.D = mk3(0.0f, 0.0f, 0.0f); r.w = 0.0f; r.tmin = r.tmax = 0.0f; r.count = 0; r.outside = true;
+    f3 acc = mk3(0.0f, 0.0f, 0.0f);
+    int np = 0;
+    // traversal state of the lane's ray
+    int node = TRAV_FIN;
+    E* top = stk;
+    const E* floor = stk;
+    uint32_t cur = NO_INST, cull = 0;
+    f3 Oc = r.O, Dc = r.D;
+    BoxRay br = box_ray(r.O, mk3(1.0f, 1.0f, 1.0f), sc.scale, sc.grid);
+    HitRec best;
+    best.t = 0.0f; best.hit = false; best.prim = 0; best.leaf = 0; best.inst = 0; best.U = best.V = 0.0f; best.ad = 1.0f;
+
+    auto start_ray = [&](bool traced) {             // TraceRay(r): set the traversal up (traced = false: a Miss without a trace)
+        best.t = r.tmax; best.hit = false; best.prim = 0; best.leaf = 0; best.inst = 0; best.U = 0.0f; best.V = 0.0f; best.ad = 1.0f;
+        cull = r.outside ? CULL_BACK : CULL_FRONT;
+        cur = NO_INST; Oc = r.O; Dc = r.D; top = stk; floor = stk;
+        br = box_ray(r.O, r.D, sc.scale, sc.grid);
+        node = traced ? 0 : TRAV_FIN;
+    };
+
+    for (;;) {
+        // ---- lanes without a pixel take the next ones of the column
+        if (cursor < TOTAL) {
+            const unsigned long long need = __ballot(!alive);
+            if (need) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                const uint32_t mine = cursor + rank;
+                if (!alive && mine < TOTAL) {
+                    pix = mine;
+                    const uint32_t yb = y0 + (pix >> 6) * 8u;
+                    const uint32_t x = x0 + compact1by1(pix & 63u), y = yb + compact1by1((pix & 63u) >> 1);
+                    if (x < a.W && y < a.H) {
+                        r = primary_ray(a, cb, x, y);
+                        acc = mk3(0.0f, 0.0f, 0.0f); np = 0;
+                        alive = true;
+                        st.pixels += 1;
+                        start_ray(col_may_hit && yb + 8u > a.hy0 && yb < a.hy1);     // the same skip rule as k_render_fused, per 8x8 block
+                    }
+                }
+                cursor += (uint32_t)__popcll(need);
+            }
+        }
+        const unsigned long long m_alive = __ballot(alive);
+        if (m_alive == 0ull) { if (cursor >= TOTAL) break; else continue; }
+        const unsigned long long m_fin = __ballot(alive && node == TRAV_FIN);
+        const unsigned long long m_node = __ballot(alive && node >= 0);
+        const unsigned long long m_leaf = m_alive & ~m_fin & ~m_node;             // holding a leaf / at the end of a subtree
+        const int n_alive = __popcll(m_alive), n_fin = __popcll(m_fin), n_node = __popcll(m_node), n_leaf = __popcll(m_leaf);
+        const int n_trav = n_node + n_leaf;
+        // which step: shade once a quarter of the live lanes wait for it (or nothing else is left); among the travelling lanes a
+        // leaf step once a quarter of them hold one (or none is at an internal node)
+        if (n_fin > 0 && (n_trav == 0 || n_fin * 8 >= n_alive * (int)a.async_shade_num)) {
+            if (alive && node == TRAV_FIN) {
+                if (best.hit) {                         // the ray in the space of the instance that was hit, as at its entry
+                    const InstDev& in = sc.insts[best.inst];
+                    f3 Oh = r.O, Dh = r.D;
+                    if (!in.identity) { Oh = xform_point(in.inv, r.O); Dh = xform_dir(in.inv, r.D); }
+                    hit_attributes(sc.pool_tris, Oh, Dh, best);
+                }
+                ++st.rays;
+                if (STATS && first_active_lane()) ++st.passes;
+                if (shade_ray<STATS, true>(sc, a, best, r, acc, np, park, st)) {
+                    start_ray(true);
+                } else {
+                    const uint32_t lx = compact1by1(pix & 63u), ly = (pix >> 6) * 8u + compact1by1((pix & 63u) >> 1);
+                    const uint32_t x = x0 + lx, y = y0 + ly;
+                    const size_t o = a.compact_out == 0u ? (size_t)y * a.W + x : (size_t)tile_local * (TILE * TILE) + ly * TILE + (wave * 8u + lx);
+                    store_pixel(a, out_rgba8, out_f32, o, acc);
+                    alive = false;
+                }
+            }
+        } else if (n_node > 0 && n_leaf * 8 < n_trav * (int)a.async_leaf_num) {
+            if (alive && node >= 0) {                   // internal-node step
+                const NodeQ q = load_node(nodes, node);
+                if (STATS) { st.cnt.nodes++; if (first_active_lane()) st.cnt.node_trips++; }
+                node = node_step(br, q, r.tmin, best.t, top, floor);
+            }
+        } else {
+            if (alive && node < 0 && node != TRAV_FIN) {    // leaf step
+                if (STATS && first_active_lane()) st.cnt.leaf_trips++;
+                if (node == TRAV_DONE) {
+                    if (cur == NO_INST) node = TRAV_FIN;
+                    else {                              // leave the instance
+                        cur = NO_INST; Oc = r.O; Dc = r.D; cull = r.outside ? CULL_BACK : CULL_FRONT; floor = stk;
+                        br = box_ray(r.O, r.D, sc.scale, sc.grid);
+                        if (top > stk) { top -= STACK_STRIDE; node = StackCodec<E>::dec(*top); } else node = TRAV_FIN;
+                    }
+                } else {
+                    const uint32_t L = (uint32_t)~node;
+                    if (L < sc.n_pool_tris) {
+                        if (STATS) st.cnt.tris++;
+                        tri_test(sc.pool_tris, L, Oc, Dc, r.tmin, cull, cur, best);
+                        if (top > floor) { top -= STACK_STRIDE; node = StackCodec<E>::dec(*top); } else node = TRAV_DONE;
+                    } else {
+                        const uint32_t ii = L - sc.n_pool_tris;
+                        const InstDev& in = sc.insts[ii];
+                        if (in.mask & 0xffu) {                                            // InstanceInclusionMask 0xff
+                            uint32_t f = r.outside ? CULL_BACK : CULL_FRONT;
+                            if (in.flags & 0x1u) f &= ~(CULL_BACK | CULL_FRONT);          // TRIANGLE_CULL_DISABLE
+                            else if (in.flags & 0x2u) {                                    // TRIANGLE_FRONT_COUNTERCLOCKWISE
+                                if (f & CULL_BACK) f = (f & ~CULL_BACK) | CULL_FRONT;
+                                else if (f & CULL_FRONT) f = (f & ~CULL_FRONT) | CULL_BACK;
+                            }
+                            cull = f; cur = ii; floor = top;
+                            if (!in.identity) { Oc = xform_point(in.inv, r.O); Dc = xform_dir(in.inv, r.D); }
+                            br = box_ray(Oc, Dc, in.scale, in.grid);
+                            node = (int)in.root;
+                        } else if (top > stk) { top -= STACK_STRIDE; node = StackCodec<E>::dec(*top); } else node = TRAV_DONE;
+                    }
+                }
+            }
+        }
+    }
+    flush_stats<STATS>(a, st, blockIdx.x * 4u + wave, lane);
+}
+
+
+template <int STACK, class E, int WPS>
+static hipError_t launch_scene_async_se(const SceneDev& sc, const DispatchDev& a, bool stats, hipStream_t s)
+{
+    const size_t lds = (size_t)4 * STACK * 64 * sizeof(E) + (size_t)4 * 2 * 8 * 64 * 4;
+    const dim3 grid(a.n_local_tiles * a.n_frames);
+    if (stats) hipLaunchKernelGGL((k_render_scene_async<STACK, true, E, WPS>), grid, dim3(256), lds, s, sc, a);
+    else       hipLaunchKernelGGL((k_render_scene_async<STACK, false, E, WPS>), grid, dim3(256), lds, s, sc, a);
+    return hipGetLastError();
+}
+
+// scenes with a TLAS; max_reflect <= 2; stack <= 39 entries; stack16: every stack entry of the scene fits 16 bits
+hipError_t launch_render_scene_async(const SceneDev& sc, const DispatchDev& a, int stack, bool stats, hipStream_t s, bool stack16)
+{
+    if (a.n_local_tiles == 0) return hipSuccess;
+    if (stack16) return stack <= 31 ? launch_scene_async_se<31, uint16_t, 4>(sc, a, stats, s) : launch_scene_async_se<39, uint16_t, 4>(sc, a, stats, s);
+    return stack <= 31 ? launch_scene_async_se<31, uint32_t, 3>(sc, a, stats, s) : launch_scene_async_se<39, uint32_t, 3>(sc, a, stats, s);
+}
+
+
 } // namespace rr

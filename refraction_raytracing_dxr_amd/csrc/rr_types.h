@@ -118,6 +118,7 @@ struct DispatchDev {
     const float* sx;                // GenerateCameraRay's screen coordinates, one per column / row (k_screen_tables):
     const float* sy;                //   sx[x] = (x + 0.5) / W * 2 - 1,  sy[y] = -((y + 0.5) / H * 2 - 1)
     uint32_t hx0, hy0, hx1, hy1;    // pixels outside this rectangle cannot see the scene: their primary ray is a Miss without a trace
+    uint32_t async_leaf_num, async_shade_num;   // k_render_scene_async: a leaf step once leaf lanes * 8 >= travelling lanes * num; a shading pass once finished lanes * 8 >= live lanes * num
     uint32_t* out_rgba8;            // world==1: W*H raster; else compact tiles
     float4*   out_f32;              // optional, same addressing
     unsigned long long* counters;   // rr::Counter slots
