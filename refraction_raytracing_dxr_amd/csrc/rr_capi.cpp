@@ -158,6 +158,7 @@ struct rr_context {
     int  dbg_stack = 0;              // RR_DEBUG_STACK
     int  dbg_ticket_blocks = 0;      // RR_DEBUG_TICKET: 1 = k_render_lds treats the whole frame as the mesh rectangle, 2 = no rectangle
     uint32_t dbg_async[2] = { 2, 2 };    // RR_DEBUG_ASYNC="leaf,shade": thresholds of k_render_scene_async in eighths (rr_types.h)
+    bool dbg_tile_order = true;      // RR_DEBUG_TILE_ORDER=0: tiles in image order (DispatchDev::rt_*)
     bool dbg_tlas32 = false;         // RR_DEBUG_TLAS32: two-level scenes keep 32-bit stack entries and register-parked rays
     int  dbg_shape = 0;              // RR_DEBUG_SHAPE: first k_render_lds workgroup shape to consider (rr_launch.h)
     std::string dbg_diag;            // RR_DEBUG_DIAG: file that receives per-wave diagnostics of Depth-1 dispatches
@@ -361,6 +362,7 @@ int rr_create(int device_ordinal, rr_context** out)
     if (const char* e = getenv("RR_DEBUG_TICKET")) ctx->dbg_ticket_blocks = atoi(e);
     if (const char* e = getenv("RR_DEBUG_SHAPE")) ctx->dbg_shape = atoi(e);
     if (const char* e = getenv("RR_DEBUG_TLAS32")) ctx->dbg_tlas32 = atoi(e) != 0;
+    if (const char* e = getenv("RR_DEBUG_TILE_ORDER")) ctx->dbg_tile_order = atoi(e) != 0;
     if (const char* e = getenv("RR_DEBUG_ASYNC")) { unsigned l = 2, sh = 2; if (sscanf(e, "%u,%u", &l, &sh) == 2 && l >= 1 && sh >= 1) { ctx->dbg_async[0] = l; ctx->dbg_async[1] = sh; } }
     if (const char* e = getenv("RR_DEBUG_DIAG")) ctx->dbg_diag = e;
     *out = ctx;
@@ -821,6 +823,17 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         mesh_screen_rect(ctx->scene_bounds, h_cams, depth, width, height, hr);
         a.hx0 = hr[0]; a.hy0 = hr[1]; a.hx1 = hr[2]; a.hy1 = hr[3];
     }
+    if (ctx->dbg_tile_order && ctx->tile_world == 1 && n_tiles < 65536u && a.hx1 > a.hx0 && a.hy1 > a.hy0) {
+        // unsharded frames: the tiles that touch the rectangle are rendered first (DispatchDev::rt_*)
+        const uint32_t tiles_y = (height + TILE - 1) / TILE;
+        const uint32_t x0 = a.hx0 / TILE, y0 = a.hy0 / TILE;
+        const uint32_t x1 = std::min(tiles_x, (a.hx1 + TILE - 1) / TILE), y1 = std::min(tiles_y, (a.hy1 + TILE - 1) / TILE);
+        if (x1 > x0 && y1 > y0 && (x1 - x0) * (y1 - y0) < n_tiles) {
+            a.rt_x0 = x0; a.rt_y0 = y0; a.rt_w = x1 - x0; a.rt_h = y1 - y0;
+            a.rt_div_w = (uint32_t)(0x100000000ull / a.rt_w) + 1u;
+            a.rt_div_o = tiles_x > a.rt_w ? (uint32_t)(0x100000000ull / (tiles_x - a.rt_w)) + 1u : 0u;
+        }
+    }
     a.cams = d_cams;
     a.n_frames = depth;
     a.blocks_per_frame = ((local + 7u) & ~7u) * 4u;
@@ -841,8 +854,8 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     a.diag = nullptr;
     unsigned long long* d_diag = nullptr;
     const char* diag_path = ctx->dbg_diag.empty() ? nullptr : ctx->dbg_diag.c_str();
-    const size_t diag_waves = std::max<size_t>((size_t)a.n_blocks * 4, (size_t)ctx->n_cus * 32);
-    if (diag_path && ctx->single_identity && (depth == 1 || ctx->dbg_kernel == 4)) {
+    const size_t diag_waves = std::max<size_t>(((size_t)a.n_blocks + (size_t)((a.hx1 - a.hx0) / 8u + 1u) * ((a.hy1 - a.hy0) / 8u + 1u) * depth) * 4 * 2, (size_t)ctx->n_cus * 32);
+    if (diag_path && ctx->single_identity) {
         RR_HIP(hipMalloc(&d_diag, diag_waves * 64));
         RR_HIP(hipMemsetAsync(d_diag, 0, diag_waves * 64, ctx->stream));
         a.diag = d_diag;
@@ -927,7 +940,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     // bound by throughput it loses (sphere.obj 483 us against 263, shell.obj 606 against 348): those stay with k_render_fused.
     const bool have_rect = a.hx1 > a.hx0 && a.hy1 > a.hy0;
     const bool paths_kernel = (ctx->dbg_kernel == 5 || (ctx->dbg_kernel == 0 && depth <= 2 && rect_share < 0.25)) && !compact && ctx->tile_world == 1 &&
-                              p.max_reflect <= 2 && need <= 39 && !a.diag && ctx->dbg_stack == 0 && have_rect;
+                              p.max_reflect <= 2 && need <= 39 && ctx->dbg_stack == 0 && have_rect;
     uint32_t pool_nodes = 0;
     if (!ctx->single_identity) {
         pool_nodes = ctx->n_insts > 1 ? ctx->n_insts - 1 : 1;

@@ -23,6 +23,7 @@ __global__ __launch_bounds__(256, TLAS ? (LPARK ? (STACK <= 30 ? 5 : 4) : RR_TLA
 {
     __shared__ uint32_t diag_trips[12];    // per wave: internal trips, leaf trips, shading passes
     const unsigned long long diag_t0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long diag_rt0 = DIAG ? __builtin_amdgcn_s_memrealtime() : 0ull;
     if (DIAG && threadIdx.x < 12) diag_trips[threadIdx.x] = 0;
     if (DIAG) __syncthreads();
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -56,7 +57,8 @@ __global__ __launch_bounds__(256, TLAS ? (LPARK ? (STACK <= 30 ? 5 : 4) : RR_TLA
         if (lane == 0) {
             unsigned long long* d = a.diag + (size_t)(blockIdx.x * 4u + wave) * 4;
             d[0] = ((unsigned long long)diag_trips[8 + wave] << 40) | ((unsigned long long)diag_trips[4 + wave] << 20) | diag_trips[wave];
-            d[1] = __builtin_amdgcn_s_memtime() - diag_t0; d[2] = mx; d[3] = diag_trips[wave] + diag_trips[4 + wave];
+            d[1] = __builtin_amdgcn_s_memtime() - diag_t0; d[2] = mx | ((diag_rt0 & 0xffffffffull) << 32);
+            d[3] = (unsigned long long)(diag_trips[wave] + diag_trips[4 + wave]) | ((__builtin_amdgcn_s_memrealtime() & 0xffffffffull) << 32);   // start / end on the 100 MHz clock all CUs share
         }
     }
     flush_stats<STATS>(a, st, blockIdx.x * 4u + wave, lane);
@@ -82,7 +84,7 @@ struct PathLeaf { float w; f3 e; };
 
 template <bool STATS, bool TLAS, class E>
 __device__ __forceinline__ PathLeaf render_path(const SceneDev& sc, const DispatchDev& a, const CamDev& cb, uint32_t x, uint32_t y,
-                                                uint32_t path, E* stk, LaneStats& st)
+                                                uint32_t path, E* stk, LaneStats& st, uint32_t* diag_lv = nullptr)
 {
     PathLeaf leaf; leaf.w = 0.0f; leaf.e = mk3(0.0f, 0.0f, 0.0f);
     f3 O = mk3(cb.cam[0], cb.cam[1], cb.cam[2]);
@@ -95,6 +97,10 @@ __device__ __forceinline__ PathLeaf render_path(const SceneDev& sc, const Dispat
         // the lane that accounts for this ray (and owns its leaf, should it be one): rays at count 0 are shared by the four
         // lanes of the pixel, rays at count 1 by the two with the same first turn
         const bool owner = count == 0u ? path == 0u : count == 1u ? (path & 1u) == 0u : true;
+        if (diag_lv) {      // diagnostic builds: lanes alive at this level, time at which it starts
+            const uint32_t n_alive = (uint32_t)__popcll(__ballot(1));
+            if (first_active_lane()) diag_lv[count < 15u ? count : 15u] = n_alive | ((uint32_t)__builtin_amdgcn_s_memrealtime() << 8);
+        }
         HitRec h;
         TravCounters cnt; cnt.nodes = 0; cnt.tris = 0;
         trace_scene<STATS, TLAS, E, GlobalNodes>(sc, O, D, tmin, tmax, outside ? CULL_BACK : CULL_FRONT, h, stk, cnt);
@@ -137,11 +143,14 @@ __device__ __forceinline__ PathLeaf render_path(const SceneDev& sc, const Dispat
     return leaf;
 }
 
-template <int STACK, bool STATS, bool TLAS>
+template <int STACK, bool STATS, bool TLAS, bool DIAG = false>
 __global__ __launch_bounds__(256, TLAS ? 5 : 8) void k_render_paths(SceneDev sc, DispatchDev a, uint32_t n_pp_blocks, uint32_t rect_bw)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    __shared__ uint32_t diag_lv[4][16];        // diagnostic builds: per wave and ray level, lanes alive | start time << 8
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const unsigned long long diag_t0 = DIAG ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    if (DIAG) { if (lane < 16u) diag_lv[wave][lane] = 0u; }
     LaneStats st;
     if (blockIdx.x < n_pp_blocks) {
         uint32_t* stk = lds + wave * (STACK * 64) + lane;
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(256, TLAS ? 5 : 8) void k_render_paths(SceneDev sc,
         st.blocks = 1u;                 // (a quarter of an 8x8 block: the per-wave cost of the issue model does not apply to this kernel)
         if (valid) {
             if (path == 0u) st.pixels = 1;
-            lf = render_path<STATS, TLAS, uint32_t>(sc, a, a.cams[frame], x, y, path, stk, st);
+            lf = render_path<STATS, TLAS, uint32_t>(sc, a, a.cams[frame], x, y, path, stk, st, DIAG ? diag_lv[wave] : nullptr);
         }
         // the pixel's colour: its leaves in the recursion's order (lanes 4*pix .. 4*pix+3)
         f3 acc = mk3(0.0f, 0.0f, 0.0f);
@@ -180,6 +189,11 @@ __global__ __launch_bounds__(256, TLAS ? 5 : 8) void k_render_paths(SceneDev sc,
             store_pixel(a, a.out_rgba8 + (size_t)bp.frame * a.frame_stride, a.out_f32 ? a.out_f32 + (size_t)bp.frame * a.frame_stride : nullptr,
                         (size_t)y * a.W + x, acc);
         }
+    }
+    if (DIAG && a.diag) {       // per wave: start, end (100 MHz), block kind, then the 16 level words
+        unsigned long long* d = a.diag + (size_t)(blockIdx.x * 4u + wave) * 12;
+        if (lane == 0) { d[0] = diag_t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = blockIdx.x < n_pp_blocks ? 1ull : 0ull; d[3] = blockIdx.x; }
+        if (lane < 8u) d[4 + lane] = (unsigned long long)diag_lv[wave][2 * lane] | ((unsigned long long)diag_lv[wave][2 * lane + 1] << 32);
     }
     flush_stats<STATS>(a, st, blockIdx.x * 4u + wave, lane);
 }
@@ -558,7 +572,8 @@ hipError_t launch_render_fused(const SceneDev& sc, const DispatchDev& a, int sta
     if (stack16 && !a.diag && sc.single_identity && stack <= 39)
         return pend <= 2 ? launch_fused_s16<2>(sc, a, stats, s) : launch_fused_s16<8>(sc, a, stats, s);
     if (a.diag) {       // diagnostic build of the reference-scene kernel (RR_DEBUG_DIAG; never used by the product path)
-        hipLaunchKernelGGL((k_render_fused<31, 2, false, false, true>), dim3(a.n_blocks), dim3(256), 4 * 31 * 64 * 4, s, sc, a);
+        if (stack <= 19) hipLaunchKernelGGL((k_render_fused<19, 2, false, false, true>), dim3(a.n_blocks), dim3(256), 4 * 19 * 64 * 4, s, sc, a);
+        else hipLaunchKernelGGL((k_render_fused<31, 2, false, false, true>), dim3(a.n_blocks), dim3(256), 4 * 31 * 64 * 4, s, sc, a);
         return hipGetLastError();
     }
     if (stack <= 19 && pend <= 2) return launch_fused_sp<19, 2>(sc, a, stats, s);
@@ -589,6 +604,7 @@ static hipError_t launch_paths_st(const SceneDev& sc, const DispatchDev& a, uint
 {
     const size_t lds = (size_t)4 * STACK * 64 * sizeof(uint32_t);
     const dim3 grid(n_pp + a.n_blocks);
+    if (a.diag && !TLAS) { hipLaunchKernelGGL((k_render_paths<STACK, false, false, true>), grid, dim3(256), lds, s, sc, a, n_pp, rect_bw); return hipGetLastError(); }
     if (stats) hipLaunchKernelGGL((k_render_paths<STACK, true, TLAS>), grid, dim3(256), lds, s, sc, a, n_pp, rect_bw);
     else       hipLaunchKernelGGL((k_render_paths<STACK, false, TLAS>), grid, dim3(256), lds, s, sc, a, n_pp, rect_bw);
     return hipGetLastError();

@@ -241,6 +241,27 @@ __device__ __forceinline__ void flush_stats(const DispatchDev& a, const LaneStat
 // the 32x8 strip one 256-thread workgroup of k_render_fused renders; strips of consecutive frames follow each other (the
 // depth slices are interleaved: mixing the slices keeps every CU on a blend of cheap background waves and expensive mesh
 // waves -- monkey.obj 1080p, Depth 16: 193 us/frame interleaved, 238 us slice after slice).
+// i-th tile of a launch in the order "rectangle first" (DispatchDev::rt_*): everything is wave-uniform scalar arithmetic
+__device__ __forceinline__ uint32_t tile_in_launch_order(const DispatchDev& a, uint32_t i)
+{
+    if (a.rt_w == 0u || i >= a.n_local_tiles) return i;
+    const uint32_t n_rect = a.rt_w * a.rt_h;
+    if (i < n_rect) {
+        const uint32_t row = a.rt_w == 1u ? i : __umulhi(i, a.rt_div_w);
+        return (a.rt_y0 + row) * a.tiles_x + a.rt_x0 + (i - row * a.rt_w);
+    }
+    uint32_t j = i - n_rect;
+    const uint32_t above = a.rt_y0 * a.tiles_x;
+    if (j < above) return j;
+    j -= above;
+    const uint32_t per_row = a.tiles_x - a.rt_w, beside = per_row * a.rt_h;
+    if (j < beside) {
+        const uint32_t row = per_row == 1u ? j : __umulhi(j, a.rt_div_o), c = j - row * per_row;
+        return (a.rt_y0 + row) * a.tiles_x + (c < a.rt_x0 ? c : c + a.rt_w);
+    }
+    return (a.rt_y0 + a.rt_h) * a.tiles_x + (j - beside);
+}
+
 struct BlockPos { uint32_t frame, tile_local, x0, y0, px0, py0; bool tile_ok; };
 __device__ __forceinline__ BlockPos wave_block_pos(const DispatchDev& a, uint32_t wb)
 {
@@ -250,6 +271,7 @@ __device__ __forceinline__ BlockPos wave_block_pos(const DispatchDev& a, uint32_
     uint32_t strip;
     block_to_tile(blk / a.n_frames, p.tile_local, strip);
     p.tile_ok = p.tile_local < a.n_local_tiles;
+    p.tile_local = tile_in_launch_order(a, p.tile_local);
     const uint32_t tile = p.tile_local * a.tile_world + a.tile_rank;
     const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     p.px0 = wave * 8u; p.py0 = strip * 8u;                         // inside the 32x32 tile

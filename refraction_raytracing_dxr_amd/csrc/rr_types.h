@@ -118,6 +118,11 @@ struct DispatchDev {
     const float* sx;                // GenerateCameraRay's screen coordinates, one per column / row (k_screen_tables):
     const float* sy;                //   sx[x] = (x + 0.5) / W * 2 - 1,  sy[y] = -((y + 0.5) / H * 2 - 1)
     uint32_t hx0, hy0, hx1, hy1;    // pixels outside this rectangle cannot see the scene: their primary ray is a Miss without a trace
+    // Order of the tiles inside a launch (wave_block_pos): the tiles that touch the rectangle first, in raster order, then the
+    // rest -- the expensive waves start at once and the launch ends on background waves, a few microseconds each, instead of on
+    // the last mesh waves (hundreds).  rt_w == 0: image order.  Tile units; rt_div_w / rt_div_o: 2^32 / d + 1 for the two
+    // divisions (exact below 65 536 tiles).
+    uint32_t rt_x0, rt_y0, rt_w, rt_h, rt_div_w, rt_div_o;
     uint32_t async_leaf_num, async_shade_num;   // k_render_scene_async: a leaf step once leaf lanes * 8 >= travelling lanes * num; a shading pass once finished lanes * 8 >= live lanes * num
     uint32_t* out_rgba8;            // world==1: W*H raster; else compact tiles
     float4*   out_f32;              // optional, same addressing
