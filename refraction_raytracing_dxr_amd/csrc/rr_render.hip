@@ -16,10 +16,9 @@
 
 namespace rr {
 
-// LPARK: the parked reflected rays live in LDS behind the stacks (two slots of 8 words per lane) instead of registers: the
-// two-level kernel is the one short of registers (96 with 35 words spilled), and with 16-bit stack entries the LDS has room.
-template <int STACK, int PEND, bool STATS, bool TLAS, bool DIAG = false, class E = uint32_t, bool LPARK = false>
-__global__ __launch_bounds__(256, TLAS ? (LPARK ? (STACK <= 30 ? 5 : 4) : RR_TLAS_WAVES_PER_SIMD(STACK)) : sizeof(E) == 2 ? 8 : RR_FUSED_WAVES_PER_SIMD(STACK)) void k_render_fused(SceneDev sc, DispatchDev a)
+// WPS: waves per SIMD the instantiation is built for (0: what its stack size leaves room for, see rr_render_common.h)
+template <int STACK, int PEND, bool STATS, bool TLAS, bool DIAG = false, class E = uint32_t, int WPS = 0>
+__global__ __launch_bounds__(256, WPS ? WPS : TLAS ? RR_TLAS_WAVES_PER_SIMD(STACK) : sizeof(E) == 2 ? 8 : RR_FUSED_WAVES_PER_SIMD(STACK)) void k_render_fused(SceneDev sc, DispatchDev a)
 {
     __shared__ uint32_t diag_trips[12];    // per wave: internal trips, leaf trips, shading passes
     const unsigned long long diag_t0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -42,8 +41,7 @@ __global__ __launch_bounds__(256, TLAS ? (LPARK ? (STACK <= 30 ? 5 : 4) : RR_TLA
     st.blocks = bp.tile_ok ? 1u : 0u;
     if (valid) {
         st.pixels = 1;
-        typename std::conditional<LPARK, LdsPark, RegPark<PEND> >::type park;
-        if constexpr (LPARK) park.base = lds + (4u * STACK * 64u * (uint32_t)sizeof(E)) / 4u + wave * (2u * 8u * 64u) + lane;
+        RegPark<PEND> park;
         const bool may_hit = DIAG || (bp.x0 + 8u > a.hx0 && bp.x0 < a.hx1 && bp.y0 + 8u > a.hy0 && bp.y0 < a.hy1);
         const f3 acc = render_pixel<STATS, TLAS, DIAG, E, GlobalNodes>(sc, a, cb, x, y, may_hit, stk, GlobalNodes{}, park, st, Diag{ &diag_trips[wave], 4 });
         const size_t o = a.compact_out == 0u ? (size_t)y * a.W + x
@@ -554,21 +552,24 @@ static hipError_t launch_fused_s16(const SceneDev& sc, const DispatchDev& a, boo
     return hipGetLastError();
 }
 
-// two-level scenes whose stack entries fit 16 bits, max_reflect <= 2: 16-bit stacks + parked rays in LDS
-template <int STACK>
+// Two-level scenes whose stack entries fit 16 bits (fewer than 32 768 pool nodes and triangles + instances) and whose trees are
+// at most 30 levels deep: 15 KB of stacks per workgroup instead of 31, so the LDS no longer caps the kernel at five waves per
+// SIMD, and the build for seven (72 registers, 64 words through scratch) is the fastest -- the 1 024-monkey grid at 2160p,
+// Depth 16: 7.51 ms per frame with 32-bit stacks (five waves), 7.23 / 6.95 / 7.24 ms built for six / seven / eight.
+// (Parking the reflected rays in LDS instead of registers -- 96 registers, five waves, a third of the spills -- measured 7.76.)
+template <int STACK, int WPS>
 static hipError_t launch_fused_tlas16(const SceneDev& sc, const DispatchDev& a, bool stats, hipStream_t s)
 {
-    const size_t lds = (size_t)4 * STACK * 64 * sizeof(uint16_t) + (size_t)4 * 2 * 8 * 64 * 4;
-    if (stats) hipLaunchKernelGGL((k_render_fused<STACK, 2, true, true, false, uint16_t, true>), dim3(a.n_blocks), dim3(256), lds, s, sc, a);
-    else       hipLaunchKernelGGL((k_render_fused<STACK, 2, false, true, false, uint16_t, true>), dim3(a.n_blocks), dim3(256), lds, s, sc, a);
+    const size_t lds = (size_t)4 * STACK * 64 * sizeof(uint16_t);
+    if (stats) hipLaunchKernelGGL((k_render_fused<STACK, 2, true, true, false, uint16_t, WPS>), dim3(a.n_blocks), dim3(256), lds, s, sc, a);
+    else       hipLaunchKernelGGL((k_render_fused<STACK, 2, false, true, false, uint16_t, WPS>), dim3(a.n_blocks), dim3(256), lds, s, sc, a);
     return hipGetLastError();
 }
 
 hipError_t launch_render_fused(const SceneDev& sc, const DispatchDev& a, int stack, int pend, bool stats, hipStream_t s, bool stack16)
 {
     if (a.n_blocks == 0) return hipSuccess;
-    if (stack16 && !a.diag && !sc.single_identity && pend <= 2 && stack <= 39)
-        return stack <= 30 ? launch_fused_tlas16<30>(sc, a, stats, s) : launch_fused_tlas16<39>(sc, a, stats, s);
+    if (stack16 && !a.diag && !sc.single_identity && pend <= 2 && stack <= 30) return launch_fused_tlas16<30, 7>(sc, a, stats, s);
     if (stack16 && !a.diag && sc.single_identity && stack <= 39)
         return pend <= 2 ? launch_fused_s16<2>(sc, a, stats, s) : launch_fused_s16<8>(sc, a, stats, s);
     if (a.diag) {       // diagnostic build of the reference-scene kernel (RR_DEBUG_DIAG; never used by the product path)

@@ -31,7 +31,7 @@ def klass(op):
 
 
 def main():
-    want = sys.argv[1] if len(sys.argv) > 1 else "k_render_fusedILi19ELi2ELb0ELb0ELb0EjE"
+    want = sys.argv[1] if len(sys.argv) > 1 else "k_render_fusedILi19ELi2ELb0ELb0ELb0EjLb0EE"
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "render.s")
         subprocess.run(["hipcc", "-x", "hip", SRC, "--offload-arch=gfx950", "-fno-gpu-rdc", "-O3", "-std=c++17", "-ffp-contract=off",
