@@ -70,14 +70,21 @@ __global__ __launch_bounds__(256, WPS ? WPS : TLAS ? RR_TLAS_WAVES_PER_SIMD(STAC
 // branches while count < max_reflect; for max_reflect <= 2 it therefore has at most four root-to-leaf paths -- refract or
 // reflect at the primary hit, refract or reflect at the next, refractions only from there on -- and each ends in at most
 // one leaf (a Miss, weight * texel; a terminal hit or a total internal reflection ends it with nothing).  Here FOUR lanes
-// share a pixel, lane p following path p (bit 1: reflect at count 0, bit 0: reflect at count 1); the four leaves are then
+// share a pixel, one in each wave of the workgroup, wave p following path p (bit 1: reflect at count 0, bit 0: reflect at
+// count 1) for the 64 pixels of the block; the four leaves are then
 // summed in the recursion's order -- TT, TR, RT, RR, the order in which k_render_fused reaches them -- with the same
 // fma sequence, a path without a leaf contributing fma(0, 0, acc) = acc.  So the frame is bit-identical, the longest chain of
 // dependent rays drops from 19 to 2 + the refraction limit, and a block's work spreads over four waves.  The primary ray is
 // traced by all four lanes and the two count-1 rays by two each (more work, which a launch of one slice has room for);
 // counters count a shared ray once.
-// A workgroup is an 8x8 pixel block inside the scene's screen rectangle (its four waves take the 4x4 quadrants); the blocks
-// outside the rectangle follow in the same launch as 32x8 strips, one Miss per pixel without a trace.
+// A workgroup is an 8x8 pixel block inside the scene's screen rectangle; the blocks outside the rectangle follow in the
+// same launch as 32x8 strips, one Miss per pixel without a trace.  Measured and rejected (monkey.obj 1080p, Depth 1, 8/2
+// bounces, us per frame; this form: 244): the four paths of a pixel in adjacent lanes of one wave, the first form of this
+// kernel (271: refracted and reflected rays in one wave diverge at once); waves that retire as they finish, the last one
+// summing, on 16-bit stacks so that more workgroups fit a CU (265; ott.obj 708 against 634) and, the other way, fewer
+// workgroups per CU (6: 292, 4: 328) -- the chains of dependent rays that decide the launch slow down when more waves
+// compete, the bulk of the frame when fewer run; s_setprio by ray depth (no effect: the waves deep in a chain are the oldest
+// on their SIMD anyway).
 struct PathLeaf { float w; f3 e; };
 
 template <bool STATS, bool TLAS, class E>
@@ -153,9 +160,10 @@ __global__ __launch_bounds__(256, TLAS ? 5 : 8) void k_render_paths(SceneDev sc,
     if (blockIdx.x < n_pp_blocks) {
         uint32_t* stk = lds + wave * (STACK * 64) + lane;
         const uint32_t frame = blockIdx.x % a.n_frames, b = blockIdx.x / a.n_frames;
-        const uint32_t x0 = a.hx0 + (b % rect_bw) * 8u + (wave & 1u) * 4u, y0 = a.hy0 + (b / rect_bw) * 8u + (wave >> 1) * 4u;
-        const uint32_t pix = lane >> 2, path = lane & 3u;
-        const uint32_t x = x0 + (pix & 3u), y = y0 + (pix >> 2);
+        // wave p follows path p of the block's 64 pixels: the lanes of a wave then trace rays of one kind (all refracted twice,
+        // all reflected then refracted, ...), which stay closer together than the four paths of one pixel do
+        const uint32_t path = wave;
+        const uint32_t x = a.hx0 + (b % rect_bw) * 8u + compact1by1(lane), y = a.hy0 + (b / rect_bw) * 8u + compact1by1(lane >> 1);
         const bool valid = x < a.W && y < a.H;
         PathLeaf lf; lf.w = 0.0f; lf.e = mk3(0.0f, 0.0f, 0.0f);
         st.blocks = 1u;                 // (a quarter of an 8x8 block: the per-wave cost of the issue model does not apply to this kernel)
@@ -163,17 +171,21 @@ __global__ __launch_bounds__(256, TLAS ? 5 : 8) void k_render_paths(SceneDev sc,
             if (path == 0u) st.pixels = 1;
             lf = render_path<STATS, TLAS, uint32_t>(sc, a, a.cams[frame], x, y, path, stk, st, DIAG ? diag_lv[wave] : nullptr);
         }
-        // the pixel's colour: its leaves in the recursion's order (lanes 4*pix .. 4*pix+3)
-        f3 acc = mk3(0.0f, 0.0f, 0.0f);
+        // the pixel's colour: its leaves in the recursion's order, handed over through the (now idle) stack space
+        float* const mine = reinterpret_cast<float*>(lds + wave * (STACK * 64)) + lane;
+        mine[0] = lf.w; mine[64] = lf.e.x; mine[128] = lf.e.y; mine[192] = lf.e.z;
+        __syncthreads();
+        if (wave == 0u && valid) {
+            f3 acc = mk3(0.0f, 0.0f, 0.0f);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int src = (int)(lane & ~3u) + p;
-            const float w = __shfl(lf.w, src, 64), ex = __shfl(lf.e.x, src, 64), ey = __shfl(lf.e.y, src, 64), ez = __shfl(lf.e.z, src, 64);
-            acc.x = fmaf(w, ex, acc.x); acc.y = fmaf(w, ey, acc.y); acc.z = fmaf(w, ez, acc.z);
-        }
-        if (valid && path == 0u)
+            for (int p = 0; p < 4; ++p) {
+                const float* src = reinterpret_cast<const float*>(lds + p * (STACK * 64)) + lane;
+                const float w = src[0], ex = src[64], ey = src[128], ez = src[192];
+                acc.x = fmaf(w, ex, acc.x); acc.y = fmaf(w, ey, acc.y); acc.z = fmaf(w, ez, acc.z);
+            }
             store_pixel(a, a.out_rgba8 + (size_t)frame * a.frame_stride, a.out_f32 ? a.out_f32 + (size_t)frame * a.frame_stride : nullptr,
                         (size_t)y * a.W + x, acc);
+        }
     } else {                                                       // a 32x8 strip outside the rectangle: Miss only
         const BlockPos bp = wave_block_pos(a, (blockIdx.x - n_pp_blocks) * 4u + wave);
         const uint32_t x = bp.x0 + compact1by1(lane), y = bp.y0 + compact1by1(lane >> 1);
