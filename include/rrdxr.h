@@ -327,8 +327,11 @@ int  rr_host_mesh_load_obj(const char* filename, rr_vertex** verts, uint32_t* n_
 #define RR_OBJ_HARDENED 0x1u
 int  rr_host_mesh_load_obj_ex(const char* filename, uint32_t flags, rr_vertex** verts, uint32_t* n_verts,
                               uint32_t** indices, uint32_t* n_indices);
-/* stbi_loadf(file,&x,&y,&n,req_comp) as called at RefractionDemo.cpp:111: Radiance .hdr and .png
- * (8/16-bit, non-interlaced), LDR expanded with pow(v/255, 2.2).  NULL on failure. */
+/* stbi_loadf(file,&x,&y,&n,req_comp) as called at RefractionDemo.cpp:111, for the two formats the demo's
+ * environment map exists in: Radiance .hdr (flat and RLE scanlines) and .png (1..16-bit gray / RGB / palette,
+ * with or without alpha, plain or Adam7-interlaced), LDR expanded with pow(v/255, 2.2) as stb does.
+ * NARROWER than stb_image (stb_image.h:1491): JPEG, BMP, TGA, PSD, GIF, PIC and PNM files are refused --
+ * NULL, like any other failure (the reference ignores load failures; the C++ mirror reports them). */
 float* rr_host_image_loadf(const char* filename, int* x, int* y, int* channels_in_file, int req_comp);
 /* Radiance RLE .hdr writer (the reference's envmap.hdr is missing from the mount). */
 int  rr_host_image_write_hdr(const char* filename, int w, int h, const float* rgb);

@@ -4,10 +4,12 @@
 // stb_image (v2.28, vendored by the reference) is third-party source and is NOT copied here; this
 // is an independent decoder for the two formats the demo's env map exists in:
 //   * Radiance RGBE ".hdr" (flat and new-RLE scanlines), value = mantissa * 2^(e-136)
-//   * PNG (non-interlaced; 1/2/4/8/16-bit gray, RGB, palette, +alpha), expanded to linear float
+//   * PNG (1/2/4/8/16-bit gray, RGB, palette, +alpha; plain or Adam7-interlaced), expanded to linear float
 //     the way stb does for LDR sources: pow(v/255, 2.2) for colour, v/255 for alpha
-// tests/test_image_io.py checks it bit-for-bit against the reference header compiled in place
-// (oracle/_ref) on envmap.png and on generated .hdr files.
+// stb_image's other formats (JPEG, BMP, TGA, PSD, GIF, PIC, PNM) are NOT decoded: rr_host_image_loadf returns NULL for them
+// (tests/test_host.py::test_image_load_failures); the demo only ever loads an .hdr (RefractionDemo.cpp:527).
+// tests/test_host.py checks the decoder bit for bit against the reference header compiled in place (oracle/_ref) on
+// envmap.png, on generated PNGs of every colour type and on generated .hdr files.
 #include "../../../include/rrdxr.h"
 
 #include <cmath>
@@ -210,7 +212,7 @@ bool decode_png(const Bytes& file, int& w, int& h, int& channels, Bytes& pix)
         else if (!memcmp(type, "IEND", 4)) break;
         pos += 12 + (size_t)len;
     }
-    if (!have_hdr || w <= 0 || h <= 0 || w > (1 << 24) || h > (1 << 24) || interlace != 0) return false;
+    if (!have_hdr || w <= 0 || h <= 0 || w > (1 << 24) || h > (1 << 24) || interlace > 1) return false;
     int file_ch;
     switch (ctype) {
     case 0: file_ch = 1; break;
@@ -226,28 +228,69 @@ bool decode_png(const Bytes& file, int& w, int& h, int& channels, Bytes& pix)
     const size_t bits_pp = (size_t)file_ch * depth;
     const size_t stride = ((size_t)w * bits_pp + 7) / 8;
     const size_t bpp = bits_pp >= 8 ? bits_pp / 8 : 1;
-    Bytes raw;
-    if (!inflate_zlib(idat, raw, (stride + 1) * h) || raw.size() < (stride + 1) * (size_t)h) return false;
-    // unfilter in place
-    Bytes img(stride * h);
-    for (int y = 0; y < h; ++y) {
-        const unsigned char* src = &raw[(stride + 1) * y];
-        unsigned char* cur = &img[stride * y];
-        const unsigned char* up = y ? &img[stride * (y - 1)] : nullptr;
-        const int ft = src[0];
-        ++src;
-        for (size_t i = 0; i < stride; ++i) {
-            int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0;
-            int v = src[i];
-            switch (ft) {
-            case 0: break;
-            case 1: v += a; break;
-            case 2: v += b; break;
-            case 3: v += (a + b) >> 1; break;
-            case 4: v += paeth(a, b, c); break;
-            default: return false;
+    // unfilter `rows` scanlines of `line` bytes each (a filter-type byte in front of every one) from src into dst
+    auto unfilter = [&](const unsigned char* src_all, unsigned char* dst_all, size_t line, int rows) -> bool {
+        for (int y = 0; y < rows; ++y) {
+            const unsigned char* src = src_all + (line + 1) * y;
+            unsigned char* cur = dst_all + line * y;
+            const unsigned char* up = y ? dst_all + line * (y - 1) : nullptr;
+            const int ft = src[0];
+            ++src;
+            for (size_t i = 0; i < line; ++i) {
+                int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0;
+                int v = src[i];
+                switch (ft) {
+                case 0: break;
+                case 1: v += a; break;
+                case 2: v += b; break;
+                case 3: v += (a + b) >> 1; break;
+                case 4: v += paeth(a, b, c); break;
+                default: return false;
+                }
+                cur[i] = (unsigned char)v;
             }
-            cur[i] = (unsigned char)v;
+        }
+        return true;
+    };
+    Bytes raw;
+    Bytes img(stride * h);
+    if (interlace == 0) {
+        if (!inflate_zlib(idat, raw, (stride + 1) * h) || raw.size() < (stride + 1) * (size_t)h) return false;
+        if (!unfilter(raw.data(), img.data(), stride, h)) return false;
+    } else {
+        // Adam7: seven reduced images, each filtered on its own, one after the other in the stream; pass p holds the pixels
+        // (x0 + i*dx, y0 + j*dy)
+        static const int x0[7] = { 0, 4, 0, 2, 0, 1, 0 }, y0[7] = { 0, 0, 4, 0, 2, 0, 1 };
+        static const int dx[7] = { 8, 8, 4, 4, 2, 2, 1 }, dy[7] = { 8, 8, 8, 4, 4, 2, 2 };
+        size_t total = 0;
+        int pw[7], ph[7];
+        for (int p = 0; p < 7; ++p) {
+            pw[p] = (w - x0[p] + dx[p] - 1) / dx[p]; ph[p] = (h - y0[p] + dy[p] - 1) / dy[p];
+            if (pw[p] > 0 && ph[p] > 0) total += (((size_t)pw[p] * bits_pp + 7) / 8 + 1) * ph[p];
+        }
+        if (!inflate_zlib(idat, raw, total) || raw.size() < total) return false;
+        size_t at = 0;
+        Bytes sub;
+        for (int p = 0; p < 7; ++p) {
+            if (pw[p] <= 0 || ph[p] <= 0) continue;
+            const size_t line = ((size_t)pw[p] * bits_pp + 7) / 8;
+            sub.assign(line * ph[p], 0);
+            if (!unfilter(&raw[at], sub.data(), line, ph[p])) return false;
+            at += (line + 1) * ph[p];
+            for (int j = 0; j < ph[p]; ++j) {
+                const unsigned char* srow = &sub[line * j];
+                unsigned char* drow = &img[stride * (size_t)(y0[p] + j * dy[p])];
+                for (int i = 0; i < pw[p]; ++i) {
+                    const size_t x = (size_t)(x0[p] + i * dx[p]);
+                    if (bits_pp >= 8) memcpy(drow + x * bpp, srow + (size_t)i * bpp, bpp);
+                    else {
+                        const size_t sb = (size_t)i * bits_pp, db = x * bits_pp;
+                        const unsigned q = (srow[sb >> 3] >> (8 - bits_pp - (sb & 7))) & ((1u << bits_pp) - 1u);
+                        const unsigned sh = (unsigned)(8 - bits_pp - (db & 7));
+                        drow[db >> 3] = (unsigned char)((drow[db >> 3] & ~(((1u << bits_pp) - 1u) << sh)) | (q << sh));
+                    }
+                }
+            }
         }
     }
     // to 8-bit samples

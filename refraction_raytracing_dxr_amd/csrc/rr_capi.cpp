@@ -891,7 +891,10 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
             RR_HIP(hipStreamSynchronize(ctx->stream));
             dfree(ctx->wf.q[0]); dfree(ctx->wf.q[1]); dfree(ctx->wf.slots); dfree(ctx->wf.hit_list); dfree(ctx->wf.counts);
             ctx->wf_pixels = 0;
-            ctx->wf.cap = (uint32_t)std::min<size_t>(px + 65536, 0x7fffffffu);     // a generation never holds two rays per pixel here
+            // (experiment only.  Generation 1 holds the refracted AND the reflected child of every covered pixel, generation 2
+            // up to four per pixel: a close-up that covers more than about half the frame overflows this queue, which the
+            // kernels report through the error flag)
+            ctx->wf.cap = (uint32_t)std::min<size_t>(px + 65536, 0x7fffffffu);
             RR_HIP(hipMalloc(&ctx->wf.q[0], (size_t)ctx->wf.cap * 48));
             RR_HIP(hipMalloc(&ctx->wf.q[1], (size_t)ctx->wf.cap * 48));
             RR_HIP(hipMalloc(&ctx->wf.slots, px * 64));

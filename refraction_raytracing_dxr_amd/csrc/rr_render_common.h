@@ -35,10 +35,13 @@ __device__ __forceinline__ uint32_t compact1by1(uint32_t v)
     return v;
 }
 
-// Blocks b and b+8 share an XCD (round-robin dispatch).  The four 32x8 strips of a tile go to one XCD
-// (they share BVH subtrees and env-map lines in that XCD's L2) while consecutive tiles go to
-// consecutive XCDs: coverage is centre-heavy (the mesh fills ~7 % of the frame but owns a third of
-// the rays), so giving an XCD a contiguous image region would leave most of the chip idle.
+// Strip-slot s of a slice -> (tile, strip): the four 32x8 strips of a tile sit eight slots apart and consecutive tiles in
+// consecutive slots.  In a launch of ONE slice workgroups b and b+8 go to the same XCD (round-robin dispatch), so a tile's
+// strips share an XCD (BVH subtrees and env-map lines in that XCD's L2) while consecutive tiles go to consecutive XCDs:
+// coverage is centre-heavy (the mesh fills ~7 % of the frame but owns a third of the rays), so giving an XCD a contiguous
+// image region would leave most of the chip idle.  With Depth slices interleaved (workgroup b renders slice b % Depth) the XCD
+// of a workgroup is (slot * Depth + slice) % 8: for Depth a multiple of 8 an XCD keeps to every eighth SLICE instead and sees
+// all of its tiles and strips.
 __device__ __forceinline__ void block_to_tile(uint32_t b, uint32_t& tile_local, uint32_t& strip)
 {
     const uint32_t xcd = b & 7u, slot = b >> 3;

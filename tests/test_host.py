@@ -249,6 +249,120 @@ def test_hdr_decode_bit_exact_vs_reference_stb(tmp_path, req):
         assert n1 == n2 == 3 and np.array_equal(mine.view(np.uint32), ref.view(np.uint32))
 
 
+def _write_adam7_png(path, arr, depth=8, palette=None):
+    """A PNG with interlace method 1 (Adam7) built by hand: arr is H x W (gray / palette indices, `depth` bits) or
+    H x W x C with C = 2 (gray+alpha), 3 (RGB), 4 (RGBA) at 8 bits.  Rows use filter types 0, 1 and 2 in turn."""
+    import struct, zlib
+    h, w = arr.shape[:2]
+    ch = 1 if arr.ndim == 2 else arr.shape[2]
+    ctype = {1: 3 if palette is not None else 0, 2: 4, 3: 2, 4: 6}[ch]
+    bits_pp = ch * depth
+    bpp = max(1, bits_pp // 8)
+
+    def pack_row(px):                       # px: n x ch samples -> bytes
+        if depth == 8:
+            return bytes(px.astype(np.uint8).reshape(-1))
+        if depth == 16:
+            return px.astype(">u2").reshape(-1).tobytes()
+        bits = "".join(format(int(v), "0%db" % depth) for v in px.reshape(-1))
+        bits += "0" * (-len(bits) % 8)
+        return bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+
+    raw = bytearray()
+    for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+        sub = arr[y0::dy, x0::dx]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        prev = None
+        for j in range(sub.shape[0]):
+            cur = pack_row(sub[j].reshape(sub.shape[1], ch))
+            ft = j % 3
+            if ft == 1:
+                out = bytes((cur[i] - (cur[i - bpp] if i >= bpp else 0)) & 255 for i in range(len(cur)))
+            elif ft == 2:
+                out = bytes((cur[i] - (prev[i] if prev is not None else 0)) & 255 for i in range(len(cur)))
+            else:
+                out = cur
+            raw += bytes([ft]) + out
+            prev = cur
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1))
+    if palette is not None:
+        png += chunk(b"PLTE", bytes(np.asarray(palette, np.uint8).reshape(-1)))
+    png += chunk(b"IDAT", zlib.compress(bytes(raw))) + chunk(b"IEND", b"")
+    with open(path, "wb") as f:
+        f.write(png)
+
+
+def _adam7_cases(rng):
+    pal = rng.integers(0, 256, (16, 3), dtype=np.uint8)
+    return {
+        "i_rgb.png": (rng.integers(0, 256, (37, 53, 3), dtype=np.uint8), 8, None),
+        "i_rgba.png": (rng.integers(0, 256, (9, 5, 4), dtype=np.uint8), 8, None),
+        "i_la.png": (rng.integers(0, 256, (16, 17, 2), dtype=np.uint8), 8, None),
+        "i_gray.png": (rng.integers(0, 256, (40, 31), dtype=np.uint8), 8, None),
+        "i_g16.png": (rng.integers(0, 65536, (11, 9), dtype=np.uint16), 16, None),
+        "i_g1.png": (rng.integers(0, 2, (13, 21), dtype=np.uint8), 1, None),
+        "i_g2.png": (rng.integers(0, 4, (7, 3), dtype=np.uint8), 2, None),
+        "i_pal4.png": (rng.integers(0, 16, (10, 19), dtype=np.uint8), 4, pal),
+        "i_tiny.png": (rng.integers(0, 256, (1, 1, 3), dtype=np.uint8), 8, None),      # six of the seven passes are empty
+        "i_thin.png": (rng.integers(0, 256, (3, 2, 3), dtype=np.uint8), 8, None),
+    }
+
+
+def test_adam7_png_decodes_to_the_image_it_was_made_from(tmp_path):
+    """Interlaced PNGs (stb_image reads them, RefractionDemo.cpp:111 goes through stbi_loadf): the seven passes are put back
+    where they belong -- checked against the pixels the file was built from, through the decoder's own LDR -> float rule."""
+    rng = np.random.default_rng(7)
+    for name, (arr, depth, pal) in _adam7_cases(rng).items():
+        _write_adam7_png(tmp_path / name, arr, depth, pal)
+        mine, n = rr.load_texture(tmp_path / name, 0)
+        if pal is not None:
+            want8 = np.asarray(pal)[arr]
+        elif depth == 16:
+            want8 = (arr >> 8).astype(np.uint8)
+        elif depth < 8:
+            want8 = (arr * {1: 255, 2: 85, 4: 17}[depth]).astype(np.uint8)
+        else:
+            want8 = arr
+        want8 = want8.reshape(arr.shape[0], arr.shape[1], -1)
+        assert mine.shape == want8.shape and n == want8.shape[2], name
+        col = want8.shape[2] - (1 if want8.shape[2] in (2, 4) else 0)               # alpha stays linear
+        want = np.empty(want8.shape, np.float32)
+        want[..., :col] = np.power(want8[..., :col].astype(np.float32) / np.float32(255.0), np.float32(2.2)).astype(np.float32)
+        if col < want8.shape[2]:
+            want[..., col:] = want8[..., col:].astype(np.float32) / np.float32(255.0)
+        assert np.allclose(mine, want, rtol=2e-6, atol=1e-7), name
+
+
+@pytest.mark.skipif(not have_ref_stb(), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("req", [0, 3])
+def test_adam7_png_bit_exact_vs_reference_stb(tmp_path, req):
+    rng = np.random.default_rng(8)
+    for name, (arr, depth, pal) in _adam7_cases(rng).items():
+        _write_adam7_png(tmp_path / name, arr, depth, pal)
+        mine, n1 = rr.load_texture(tmp_path / name, req)
+        ref, n2 = ref_loadf(tmp_path / name, req)
+        assert n1 == n2 and mine.shape == ref.shape, name
+        assert np.array_equal(mine.view(np.uint32), ref.view(np.uint32)), name
+
+
+def test_formats_outside_the_asset_surface_are_refused(tmp_path):
+    """rr_host_image_loadf decodes Radiance .hdr and PNG only (include/rrdxr.h); the other formats stbi_loadf accepts
+    (stb_image.h:1491) come back as a clean failure, never as a crash or a wrong image."""
+    from PIL import Image
+    img = Image.fromarray(np.arange(48, dtype=np.uint8).reshape(4, 4, 3), "RGB")
+    for name, fmt in (("a.jpg", "JPEG"), ("a.bmp", "BMP"), ("a.tga", "TGA"), ("a.gif", "GIF"), ("a.ppm", "PPM")):
+        img.save(tmp_path / name, fmt)
+        with pytest.raises(rr.RRError):
+            rr.load_texture(tmp_path / name)
+    (tmp_path / "interlace2.png").write_bytes(b"\x89PNG\r\n\x1a\n" + b"\0\0\0\x0dIHDR" + b"\0\0\0\x02\0\0\0\x02\x08\x02\0\0\x02" + b"\0" * 20)
+    with pytest.raises(rr.RRError):
+        rr.load_texture(tmp_path / "interlace2.png")      # interlace method 2 does not exist
+
+
 def test_image_load_failures(tmp_path):
     with pytest.raises(rr.RRError):
         rr.load_texture(tmp_path / "nope.hdr")
