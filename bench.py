@@ -42,7 +42,7 @@ VALU_CYCLES_PER_TRIP = {"node": 30.9 * 4.2,                               # 30.9
                         "leaf": 30.9 * 2.2 + 27.9 * 4.2 + 0.4 * 8.0,      # 59.2: Moller-Trumbore is mostly f32 mul / fma
                         "pass": 117.9 * 2.2 + 111.3 * 4.2 + 10.1 * 8.0,   # 239.2 per shading pass (ray set-up, ClosestHit / Miss)
                         "wave": 111.4 * 4.2}                              # per 8x8 block: RayGen, addressing, store
-ROOFLINE_KERNEL = "k_render_fused<19, 2, false, false, false, unsigned int>"
+ROOFLINE_KERNEL = "k_render_fused<19, 2, false, false, false, unsigned int, 0>"
 
 
 def algorithmic_bytes(st):
@@ -164,6 +164,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12288)     # 1.3 s of frames on one GPU: the timed region is not launch jitter
     ap.add_argument("--warmup", type=int, default=192)      # three launches: both render lanes and all three buffer sets of the N>1 pipeline
+    ap.add_argument("--prewarm", type=int, default=512,
+                    help="frames rendered before the --warmup steps, untimed and reported as config.prewarm_steps: a fresh box starts at "
+                         "its idle clocks and a --warmup of a few frames (half a millisecond) ends before they have come up")
     ap.add_argument("--no-depth1", action="store_true", help="skip the reference's own shape, one DispatchRays per frame (32 launches, ~15 ms)")
     ap.add_argument("--no-configs", action="store_true", help="skip the single-GPU records of the other BASELINE configurations (C1, C2, C4, C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -225,6 +228,8 @@ def main():
         dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
     if world == 1 and not force_sharded:
         r.set_tile_partition(0, 1)
+        if args.prewarm > 0:
+            r.render_orbit(W, H, args.prewarm, angle=0.01, params=params, frames_per_dispatch=F)     # clocks up, buffers allocated
         r.render_orbit(W, H, Wm, angle=0.01, params=params, frames_per_dispatch=F)      # warmup, untimed
         barrier()
         t0 = time.perf_counter()
@@ -242,6 +247,8 @@ def main():
         Fn = args.frames_per_dispatch * max(1, min(world // 2, 4))
         sf = rr.dist.ShardedFrames(r, W, H, rank, world, torch.device("cuda", local_rank), Fn, always_collective=force_sharded,
                                    rotate_root=args.rotate_root)
+        if args.prewarm > 0:
+            sf.render_orbit(args.prewarm, angle=0.01, params=params)
         sf.render_orbit(Wm, angle=0.01, params=params)
         barrier()
         t0 = time.perf_counter()
@@ -284,14 +291,17 @@ def main():
         # share cache lines, so a launch must hold consecutive frames to be a launch of the timed loop)
         n_launch = max(1, min(K, 512) // Fl)
         starts = [0.01 + 0.01 * ((K // n_launch) * j) for j in range(n_launch)]
+        reps = max(1, 8 // n_launch)    # a short run (K < 64: one launch per pass) is timed over several passes, not one sample
         for flag in (rr.DISPATCH_COLLECT_STATS, rr.DISPATCH_TIME_KERNEL):
-            for j, a0 in enumerate(starts):
-                r.render_orbit(W, H, Fl, angle=a0, frames_per_dispatch=Fl, params=rr.default_params(
-                    max_refract=MAX_REFRACT, max_reflect=MAX_REFLECT, flags=flag | (rr.DISPATCH_KEEP_COUNTERS if j else 0)))
+            for rep in range(reps if flag == rr.DISPATCH_TIME_KERNEL else 1):
+                for j, a0 in enumerate(starts):
+                    r.render_orbit(W, H, Fl, angle=a0, frames_per_dispatch=Fl, params=rr.default_params(
+                        max_refract=MAX_REFRACT, max_reflect=MAX_REFLECT, flags=flag | (rr.DISPATCH_KEEP_COUNTERS if j else 0)))
             if flag == rr.DISPATCH_COLLECT_STATS:
                 sst = r.stats()                                             # exact counters, summed over the n_launch launches
         kms, kn = r.kernel_time()                                           # HIP events around each launch, on the launch stream
         kernel_us = kms / kn * 1e3
+        kn = n_launch                                                       # the counters cover one pass
         render_kernel = int(r.stats().render_kernel)                        # which kernel those launches were
         k1ms, k1n = None, 0
         if not args.no_depth1:   # the reference's own shape, one DispatchRays per frame (RefractionDemo.cpp:589-594: Depth = 1)
@@ -318,7 +328,7 @@ def main():
                                      % os.path.relpath(cands[-1], ROOT)}
             except Exception:
                 traffic = None
-        kernel_names = {0: ROOFLINE_KERNEL, 1: "k_render_lds<12, 2, false> (the scene's tuning chose it; the issue model was fitted on k_render_fused)",
+        kernel_names = {0: ROOFLINE_KERNEL, 1: "k_render_lds<12, 2, false, false> (RR_DEBUG_KERNEL=lds; the issue model was fitted on k_render_fused)",
                         2: "k_render_paths"}
         roofline = {"bound": "valu_issue", "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "G SIMD-cycles/s",
                     "frac": round(frac, 4), "traffic": traffic,
@@ -388,6 +398,7 @@ def main():
                        "rays_per_frame": round(total_rays / K, 1),
                        "parallelism": "tiles32x32-roundrobin-x%d%s" % (world, "-rotating-root" if args.rotate_root and world > 1 else ""),
                        "frames_per_dispatch": min(K, F if world == 1 else F * max(1, min(world // 2, 4))),
+                       "prewarm_steps": args.prewarm,
                        "launch_shape": "DispatchRays(W, H, Depth = frames_per_dispatch): every frame complete in its own buffer; the "
                                        "reference's own shape, Depth 1, is roofline.depth1_kernel_us"},
             "device_region_ms_per_step": round(region_ms / K, 5) if region_ms is not None else None,

@@ -115,6 +115,14 @@ struct rr_context {
     bool cam_set = false;
     CamDev* d_cams = nullptr;        // device-side constant buffer(s), one per depth slice
     size_t cams_cap = 0;
+    // page-locked staging for the constants (a copy from pageable memory makes the runtime stage it itself, a few hundred
+    // microseconds in front of every launch): four slots in turn, each guarded by an event recorded behind its copy
+    static constexpr int CAM_SLOTS = 4;
+    void*      h_cams[CAM_SLOTS] = {};
+    size_t     h_cams_cap[CAM_SLOTS] = {};
+    hipEvent_t h_cams_ev[CAM_SLOTS] = {};
+    bool       h_cams_busy[CAM_SLOTS] = {};
+    uint32_t   h_cams_next = 0;
 
     uint32_t tile_rank = 0, tile_world = 1;
 
@@ -146,10 +154,6 @@ struct rr_context {
     // kernel by 6 % all round the orbit; monkey.obj: the L1-fed one by 2 %), and which does depends on how busy the texture
     // path is, not on anything the host can see.  So the first two eligible launches of a scene are timed with HIP events, one
     // on each kernel (adjacent slices of the same orbit), and the faster per slice renders the rest.  Frames are bit-identical.
-    int        tune_state = 0;       // 0 nothing tried, 1 fused trial issued, 2 LDS trial issued, 3 decided
-    hipEvent_t tune_ev[4] = {};
-    uint32_t   tune_depth[2] = { 0, 0 };
-    bool       tune_lds = false;
     uint32_t   last_kernel = 0;      // render kernel of the last dispatch: 0 k_render_fused, 1 k_render_lds, 2 k_render_paths, 3 experimental
     uint32_t* d_tickets = nullptr;   // k_render_lds ticket words: one block per stream a launch can be on (lanes, then the context's stream)
 
@@ -387,10 +391,10 @@ int rr_destroy(rr_context* ctx)
     dfree(ctx->wf.q[0]); dfree(ctx->wf.q[1]); dfree(ctx->wf.slots); dfree(ctx->wf.hit_list); dfree(ctx->wf.counts);
     dfree(ctx->d_assembled); dfree(ctx->d_cnt); dfree(ctx->d_tickets); dfree(ctx->d_screen);
     for (uint32_t l = 0; l <= rr_context::MAX_LANES; ++l) dfree(ctx->d_park[l]); dfree(ctx->d_rays); dfree(ctx->d_hits); dfree(ctx->d_cams);
+    for (int k = 0; k < rr_context::CAM_SLOTS; ++k) { if (ctx->h_cams[k]) (void)hipHostFree(ctx->h_cams[k]); if (ctx->h_cams_ev[k]) (void)hipEventDestroy(ctx->h_cams_ev[k]); }
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
-    for (hipEvent_t e : ctx->tune_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return RR_OK;
@@ -649,7 +653,6 @@ int rr_build_tlas(rr_context* ctx, const rr_instance_desc* instances, uint32_t n
     ctx->single_identity = n == 1 && host[0].identity && (d0.hitgroup_flags >> 24) == 0 && ((d0.instance_id_mask >> 24) & 0xffu) != 0;
     if (scene_stack_need(ctx) > 64) return fail(ctx, RR_ERR_UNSUPPORTED, "rr_build_tlas: TLAS+BLAS deeper than the 64-entry stack");
     ctx->tlas_built = true;
-    ctx->tune_state = 0;
     return RR_OK;
 }
 
@@ -910,32 +913,11 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     const uint32_t node_bytes = m0 ? (m0->n_tris > 1 ? m0->n_tris - 1 : 1) * (uint32_t)sizeof(QNode) : 0;
     // share of the frame in which the scene can be seen at all in these slices
     const double rect_share = (double)(a.hx1 - a.hx0) * (double)(a.hy1 - a.hy0) / ((double)width * (double)height);
-    // k_render_lds for launches of many slices, where the scene's tuning says so (rr_context::tune_state).  A launch of few
-    // slices ends on its most expensive blocks and pays for 768 waves sharing a ticket word: the hardware's own workgroup
-    // dispatch does better there.  RR_DEBUG_KERNEL=lds forces it wherever it fits, =fused never uses it.
+    // k_render_lds (persistent workgroups, the BLAS's nodes in LDS) is an alternative for the reference's small meshes that
+    // measures within 1-3 % of k_render_fused either way (monkey.obj Depth 64: 5.71 against 5.68 ms per launch); it is kept
+    // behind RR_DEBUG_KERNEL=lds, for the parity tests and for experiments, and never chosen by itself.
     const bool lds_fits = m0 && ctx->dbg_stack == 0 && m0->n_tris < 32768u && lds_kernel_shape(node_bytes, need + 1, nullptr, ctx->dbg_shape) >= 0;
     bool lds_kernel = lds_fits && ctx->dbg_kernel == 4;
-    int tune_slot = -1;             // this launch is one of the two trials: bracket it with events
-    bool on_lane = false;           // lanes overlap their launches: no place for a timing trial
-    for (uint32_t l = 0; l < rr_context::MAX_LANES; ++l) if (ctx->lane_stream[l] && ctx->stream == ctx->lane_stream[l]) on_lane = true;
-    if (lds_fits && ctx->dbg_kernel == 0 && depth >= 32) {
-        const bool may_try = !stats && !timed_request(p) && !on_lane;
-        if (ctx->tune_state == 2 && hipEventQuery(ctx->tune_ev[3]) == hipSuccess) {       // both trials done: decide
-            float ms_f = 0.0f, ms_l = 0.0f;
-            if (hipEventElapsedTime(&ms_f, ctx->tune_ev[0], ctx->tune_ev[1]) == hipSuccess &&
-                hipEventElapsedTime(&ms_l, ctx->tune_ev[2], ctx->tune_ev[3]) == hipSuccess && ms_f > 0.0f && ms_l > 0.0f)
-                ctx->tune_lds = ms_l / (float)ctx->tune_depth[1] < 0.97f * (ms_f / (float)ctx->tune_depth[0]);     // a tie stays with k_render_fused
-            ctx->tune_state = 3;
-        }
-        if (ctx->tune_state == 0 && may_try) { tune_slot = 0; }
-        else if (ctx->tune_state == 1 && may_try) { tune_slot = 1; lds_kernel = true; }
-        else if (ctx->tune_state == 3) lds_kernel = ctx->tune_lds;
-        if (tune_slot >= 0) {
-            for (int k = 0; k < 4; ++k) if (!ctx->tune_ev[k]) RR_HIP(hipEventCreate(&ctx->tune_ev[k]));
-            ctx->tune_depth[tune_slot] = depth;
-            RR_HIP(hipEventRecord(ctx->tune_ev[tune_slot * 2], ctx->stream));
-        }
-    }
     // Launches of one or two slices whose scene is small on screen last as long as their most expensive wave: there the
     // path-parallel kernel (four lanes per pixel inside the scene's screen rectangle: a fifth of the longest chain of
     // dependent rays, four waves per block) wins -- monkey.obj 1080p Depth 1: 268 us against 471, ott.obj 626 against 1 419.
@@ -1013,10 +995,6 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         // (the two-level 16-bit-stack builds are sized by the tree itself: 30 entries still leave five workgroups per CU)
         RR_HIP(launch_render_fused(sc, a, !ctx->single_identity && stack16 && ctx->dbg_stack == 0 ? (int)need : stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream, stack16));
     }
-    if (tune_slot >= 0) {
-        RR_HIP(hipEventRecord(ctx->tune_ev[tune_slot * 2 + 1], ctx->stream));
-        ctx->tune_state = tune_slot + 1;
-    }
     if (timed) {
         RR_HIP(hipEventRecord(ctx->kev[(size_t)ctx->kev_used * 2 + 1], ctx->stream));
         ++ctx->kev_used;
@@ -1050,7 +1028,20 @@ int upload_cams(rr_context* ctx, const rr_scene_constants* c, size_t n)
 {
     static_assert(sizeof(CamDev) == sizeof(rr_scene_constants), "constant buffer layout");
     if (int r = ensure_cams(ctx, n)) return r;
-    RR_HIP(hipMemcpyAsync(ctx->d_cams, c, n * sizeof(CamDev), hipMemcpyHostToDevice, ctx->stream));   // copy_to_buffer, :566
+    const int slot = (int)(ctx->h_cams_next++ % rr_context::CAM_SLOTS);
+    if (ctx->h_cams_busy[slot]) { RR_HIP(hipEventSynchronize(ctx->h_cams_ev[slot])); ctx->h_cams_busy[slot] = false; }
+    if (ctx->h_cams_cap[slot] < n) {
+        if (ctx->h_cams[slot]) (void)hipHostFree(ctx->h_cams[slot]);
+        ctx->h_cams[slot] = nullptr; ctx->h_cams_cap[slot] = 0;
+        const size_t cap = n < 64 ? 64 : n;
+        RR_HIP(hipHostMalloc(&ctx->h_cams[slot], cap * sizeof(CamDev), hipHostMallocDefault));
+        ctx->h_cams_cap[slot] = cap;
+    }
+    if (!ctx->h_cams_ev[slot]) RR_HIP(hipEventCreateWithFlags(&ctx->h_cams_ev[slot], hipEventDisableTiming));
+    memcpy(ctx->h_cams[slot], c, n * sizeof(CamDev));
+    RR_HIP(hipMemcpyAsync(ctx->d_cams, ctx->h_cams[slot], n * sizeof(CamDev), hipMemcpyHostToDevice, ctx->stream));   // copy_to_buffer, :566
+    RR_HIP(hipEventRecord(ctx->h_cams_ev[slot], ctx->stream));
+    ctx->h_cams_busy[slot] = true;
     return RR_OK;
 }
 

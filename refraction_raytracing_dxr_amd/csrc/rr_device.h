@@ -85,11 +85,15 @@ __device__ __forceinline__ uint32_t ftou(float f)
 
 // typed UAV store to R8G8B8A8_UNORM (RefractionDemo.cpp:431): NaN -> 0, clamp, floor(x*255 + 0.5) (the conversion truncates,
 // which is the floor of a positive number)
+// Written without branches (every wave ends with three of these): max(x, 0) is 0 for a NaN and for anything below 0 -- the
+// conversion of 0 * 255 + 0.5 is 0 --, min(.., 1) gives 1 * 255 + 0.5 = 255.5 -> 255 for anything from 1 up, and a value in
+// between goes through the very operations the oracle performs (oracle/rr_oracle.c: rro_unorm8).
 __device__ __forceinline__ uint32_t unorm8(float x)
 {
-    if (!(x > 0.0f)) return 0u;
-    if (x >= 1.0f) return 255u;
-    return ftou(x * 255.0f + 0.5f);
+    float c;
+    asm("v_max_f32 %0, %1, 0" : "=v"(c) : "v"(x));
+    asm("v_min_f32 %0, %1, 1.0" : "=v"(c) : "v"(c));
+    return ftou(c * 255.0f + 0.5f);
 }
 
 // ---- TraceRay ------------------------------------------------------------------------------
@@ -522,10 +526,21 @@ __device__ __forceinline__ f3 shading_normal(const SceneDev& sc, const HitRec& h
     return normalize3(Nr);
 }
 
+// Sum over the wave, for callers with ALL 64 lanes active (the kernels call it once, at their end): seven DPP adds -- inside
+// each row of 16 lanes (row_shr 1, 2, 3, then 4 and 8 under bank masks), then row_bcast 15 / 31 carry the row totals on -- leave
+// the total in lane 63.  No LDS round trips (six dependent ds_bpermute were the last 600 cycles of every wave's life).
+// Returned wave-uniform.
 __device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v)
 {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
+    uint32_t t;
+    t = v + __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, true);          // row_shr:1
+    t = t + __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, true);          // row_shr:2
+    t = t + __builtin_amdgcn_update_dpp(0u, v, 0x113, 0xf, 0xf, true);          // row_shr:3
+    t = t + __builtin_amdgcn_update_dpp(0u, t, 0x114, 0xf, 0xe, true);          // row_shr:4, banks 1..3
+    t = t + __builtin_amdgcn_update_dpp(0u, t, 0x118, 0xf, 0xc, true);          // row_shr:8, banks 2..3
+    t = t + __builtin_amdgcn_update_dpp(0u, t, 0x142, 0xa, 0xf, true);          // row_bcast:15 into rows 1 and 3
+    t = t + __builtin_amdgcn_update_dpp(0u, t, 0x143, 0xc, 0xf, true);          // row_bcast:31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)t, 63);
 }
 
 } // namespace rr

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256, WPS ? WPS : TLAS ? RR_TLAS_WAVES_PER_SIMD(STAC
     if (DIAG && threadIdx.x < 12) diag_trips[threadIdx.x] = 0;
     if (DIAG) __syncthreads();
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;      // wave: uniform, so that everything derived from it is scalar
     E* stk = reinterpret_cast<E*>(lds) + wave * (STACK * 64) + lane;
 
     const BlockPos bp = wave_block_pos(a, blockIdx.x * 4u + wave);
@@ -41,9 +41,21 @@ __global__ __launch_bounds__(256, WPS ? WPS : TLAS ? RR_TLAS_WAVES_PER_SIMD(STAC
     st.blocks = bp.tile_ok ? 1u : 0u;
     if (valid) {
         st.pixels = 1;
-        RegPark<PEND> park;
         const bool may_hit = DIAG || (bp.x0 + 8u > a.hx0 && bp.x0 < a.hx1 && bp.y0 + 8u > a.hy0 && bp.y0 < a.hy1);
-        const f3 acc = render_pixel<STATS, TLAS, DIAG, E, GlobalNodes>(sc, a, cb, x, y, may_hit, stk, GlobalNodes{}, park, st, Diag{ &diag_trips[wave], 4 });
+        f3 acc;
+        if (!may_hit) {
+            // A block outside the scene's screen rectangle (nine in ten on the reference's scenes): RayGen and one Miss, with none
+            // of the ray-tree machinery -- no traversal state, no parked rays, nothing spilled -- and the same arithmetic:
+            // payload.color = 0 + 1 * texel (hlsl:57-62, 127-137)
+            const f3 D = camera_ray_dir(cb.M, a.sx[x], a.sy[y]);
+            st.rays = 1;
+            if (STATS) { st.miss = 1; if (first_active_lane()) st.passes = 1; }
+            const f3 e = env_lookup(sc, D);
+            acc = mk3(fmaf(1.0f, e.x, 0.0f), fmaf(1.0f, e.y, 0.0f), fmaf(1.0f, e.z, 0.0f));
+        } else {
+            RegPark<PEND> park;
+            acc = render_pixel<STATS, TLAS, DIAG, E, GlobalNodes>(sc, a, cb, x, y, true, stk, GlobalNodes{}, park, st, Diag{ &diag_trips[wave], 4 });
+        }
         const size_t o = a.compact_out == 0u ? (size_t)y * a.W + x
                                             : (size_t)bp.tile_local * (TILE * TILE) + (bp.py0 + ly) * TILE + (bp.px0 + lx);
         store_pixel(a, out_rgba8, out_f32, o, acc);
@@ -153,7 +165,7 @@ __global__ __launch_bounds__(256, TLAS ? 5 : 8) void k_render_paths(SceneDev sc,
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ uint32_t diag_lv[4][16];        // diagnostic builds: per wave and ray level, lanes alive | start time << 8
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;      // wave: uniform, so that everything derived from it is scalar
     const unsigned long long diag_t0 = DIAG ? __builtin_amdgcn_s_memrealtime() : 0ull;
     if (DIAG) { if (lane < 16u) diag_lv[wave][lane] = 0u; }
     LaneStats st;
@@ -241,7 +253,7 @@ __global__ __launch_bounds__(NW * 64, NW * WGS / 4) void k_render_lds(SceneDev s
     }
     __syncthreads();
     const unsigned long long diag_t1 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;      // wave: uniform, so that everything derived from it is scalar
     const LdsNodes ns{ reinterpret_cast<const char*>(lds) };
     MemPark park{ q.park + (size_t)(blockIdx.x * NW + wave) * ((size_t)q.park_slots * 8 * 64) + lane };
     E* stk = reinterpret_cast<E*>(reinterpret_cast<char*>(lds) + q.node_bytes) + wave * (q.stack_entries * 64u) + lane;
@@ -388,7 +400,7 @@ __global__ __launch_bounds__(256) void k_trace_rays(SceneDev sc, const rr_ray_de
                                                     uint32_t* error_flag)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;      // wave: uniform, so that everything derived from it is scalar
     uint32_t* stk = lds + wave * (STACK * 64) + lane;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;

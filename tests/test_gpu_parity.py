@@ -254,6 +254,37 @@ def test_out_of_range_texel_through_dispatch_rays(gpu):
         assert rgba[0, 0, 0] == (0 if expect == 0.0 else 191)
 
 
+def test_unorm8_store_edges_through_dispatch_rays(gpu):
+    """The typed UAV store to R8G8B8A8_UNORM (RefractionDemo.cpp:431; hlsl:62): NaN -> 0, below 0 -> 0, from 1 up -> 255,
+    floor(x * 255 + 0.5) in between -- a frame of Misses over an env map whose texels ARE the edge values (the kernel's
+    store is written without branches), RGBA8 against the oracle's and against the rule itself."""
+    m = load("cube.obj")
+    vals = np.array([np.nan, -np.inf, -1.0, -1e-30, -0.0, 0.0, 1e-30, 0.5 / 255, np.nextafter(np.float32(0.5 / 255), np.float32(1)),
+                     np.nextafter(np.float32(0.5 / 255), np.float32(0)), 1.5 / 255, 0.49999997, 0.5, 0.50196078, 254.5 / 255,
+                     np.nextafter(np.float32(254.5 / 255), np.float32(0)), np.nextafter(np.float32(1), np.float32(0)), 1.0,
+                     np.nextafter(np.float32(1), np.float32(2)), 2.0, 1e30, np.inf, 0.1, 0.2, 0.3, 0.7, 0.9, 0.999, 0.25, 0.75,
+                     0.003, 0.996], np.float32)
+    ii, jj = np.meshgrid(np.arange(128), np.arange(256), indexing="ij")
+    env = np.stack([vals[(ii * 7 + jj * 13) % 32], vals[(ii * 11 + jj * 5 + 3) % 32], vals[(ii * 3 + jj * 17 + 9) % 32]], axis=-1).astype(np.float32)
+    gpu_scene(gpu, [m], env)
+    s = oracle_scene([m], env)
+    sc = rr.camera_orbit(0.01)
+    sc.camera_loc[0] += 40.0; sc.camera_loc[1] += 40.0            # far from the cube: every pixel is a Miss
+    gpu.set_camera(sc)
+    W, H = 96, 64
+    gpu.dispatch_rays(W, H, rr.default_params(flags=rr.DISPATCH_FLOAT_OUTPUT | rr.DISPATCH_COLLECT_STATS))
+    rgba, f32 = gpu.read_frame(want_float=True)
+    assert gpu.stats().hits == 0 and gpu.stats().misses == W * H
+    ref = s.render(np.array(sc.proj_inv, np.float32), np.array(sc.camera_loc, np.float32), W, H, O.default_params(use_bvh=1, accum_mode=1))
+    assert np.array_equal(rgba, ref["rgba8"])
+    x = f32[..., :3]
+    with np.errstate(invalid="ignore"):
+        want = np.where(~(x > 0), 0, np.where(x >= 1, 255, np.floor(x * np.float32(255.0) + np.float32(0.5)))).astype(np.uint8)
+    assert np.array_equal(rgba[..., :3], want) and (rgba[..., 3] == 255).all()
+    seen = set(np.unique(rgba[..., :3]))
+    assert {0, 1, 127, 128, 254, 255} <= seen                     # the frame really visits the edges
+
+
 @pytest.mark.skipif(not experimental_build(), reason="the product library does not contain the experiments (build with RR_EXPERIMENTAL=1)")
 def test_experimental_wavefront_kernels_render_the_same_frames(tmp_path):
     """RR_DEBUG_KERNEL=wavefront (queue-per-bounce kernels kept for comparison): bit-identical frames to
