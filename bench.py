@@ -34,14 +34,17 @@ N_SIMD, CLOCK_GHZ = 1024, 2.4    # 256 CUs x 4 SIMD-32, 2.4 GHz max clock (MI355
 # quarter-rate one on gfx950 (tools/ubench_valu.hip, profiles/r02_ubench_valu.txt: v_fma_f32 / v_mul_f32 2.2 cycles per
 # wave64 instruction per SIMD, v_cndmask / v_fma_mix_f32 / v_max3 / v_min / v_cmp / v_bfi 4.2, transcendental 8).  A 64-lane
 # wave issues one internal-node step, one triangle test or one shading pass per loop trip however many lanes take part, so
-# its issue time is  node_trips * C_NODE + leaf_trips * C_LEAF + shade_passes * C_PASS + waves * C_WAVE  SIMD cycles, with
-# per-trip instruction counts fitted against the PMC counters SQ_INSTS_VALU / _ADD_F32 / _MUL_F32 / _FMA_F32 / _TRANS_F32
-# of six workloads (tools/fit_valu.sh, tools/fit_valu.py; residual <= 0.2 %, profiles/r02_valu_fit.txt) and priced with the
-# class costs above.  The trip counters are exact and come from the RR_DISPATCH_COLLECT_STATS launches of the same frames.
-VALU_CYCLES_PER_TRIP = {"node": 30.9 * 4.2,                               # 30.9 instructions, all quarter rate (12 of them v_fma_mix_f32)
-                        "leaf": 30.9 * 2.2 + 27.9 * 4.2 + 0.4 * 8.0,      # 59.2: Moller-Trumbore is mostly f32 mul / fma
-                        "pass": 117.9 * 2.2 + 111.3 * 4.2 + 10.1 * 8.0,   # 239.2 per shading pass (ray set-up, ClosestHit / Miss)
-                        "wave": 111.4 * 4.2}                              # per 8x8 block: RayGen, addressing, store
+# its issue time is  node_trips * C_NODE + leaf_trips * C_LEAF + passes * C_PASS + waves * C_WAVE + background_waves * C_BG
+# SIMD cycles (a background wave -- a block outside the scene's screen rectangle, RayGen + one Miss on a branch of its own
+# -- is counted in the last term only), with per-trip instruction counts fitted against the PMC counters SQ_INSTS_VALU /
+# _ADD_F32 / _MUL_F32 / _FMA_F32 / _TRANS_F32 of seven workloads of this kernel (tools/fit_valu.sh, tools/fit_valu.py;
+# residual <= 1.2 %, profiles/r02_valu_fit.txt) and priced with the class costs above.  The trip counters are exact and come
+# from the RR_DISPATCH_COLLECT_STATS launches of the same frames.
+VALU_CYCLES_PER_TRIP = {"node": 130.4,      # 30.5 instructions, all quarter rate (12 of them v_fma_mix_f32)
+                        "leaf": 194.9,      # 61.3: Moller-Trumbore is mostly f32 mul / fma
+                        "pass": 856.4,      # 250.0 per shading pass of a traced wave (ray set-up, ClosestHit / Miss)
+                        "wave": 299.6,      # 70.7 per traced 8x8 block: RayGen, addressing, store
+                        "bg": 1013.1}       # 280.5 per background block: RayGen, Miss, store
 ROOFLINE_KERNEL = "k_render_fused<19, 2, false, false, false, unsigned int, 0>"
 
 
@@ -62,7 +65,9 @@ def survey_formula_bytes(st):
 
 def valu_issue_cycles(st):
     c = VALU_CYCLES_PER_TRIP
-    return st.node_trips * c["node"] + st.leaf_trips * c["leaf"] + st.shade_passes * c["pass"] + st.waves * c["wave"]
+    bg = st.background_waves
+    return (st.node_trips * c["node"] + st.leaf_trips * c["leaf"] + (st.shade_passes - bg) * c["pass"] + (st.waves - bg) * c["wave"]
+            + bg * c["bg"])
 
 
 def xf(tx, ty, tz, s=1.0):
@@ -333,20 +338,24 @@ def main():
         roofline = {"bound": "valu_issue", "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "G SIMD-cycles/s",
                     "frac": round(frac, 4), "traffic": traffic,
                     "kernel": kernel_names.get(render_kernel, "?"), "kernel_us": round(kernel_us, 2), "frames_per_launch": Fl,
-                    "model": "node_trips*%.1f + leaf_trips*%.1f + shade_passes*%.1f + waves*%.1f SIMD cycles (profiles/r02_valu_fit.txt, "
-                             "profiles/r02_ubench_valu.txt); %d SIMDs x %.1f GHz" % (
+                    "model": "node_trips*%.1f + leaf_trips*%.1f + (shade_passes - background_waves)*%.1f + (waves - background_waves)*%.1f + "
+                             "background_waves*%.1f SIMD cycles (profiles/r02_valu_fit.txt, profiles/r02_ubench_valu.txt); %d SIMDs x %.1f GHz" % (
                                  VALU_CYCLES_PER_TRIP["node"], VALU_CYCLES_PER_TRIP["leaf"], VALU_CYCLES_PER_TRIP["pass"],
-                                 VALU_CYCLES_PER_TRIP["wave"], N_SIMD, CLOCK_GHZ),
+                                 VALU_CYCLES_PER_TRIP["wave"], VALU_CYCLES_PER_TRIP["bg"], N_SIMD, CLOCK_GHZ),
                     "wave_trips_per_launch": {"node": int(sst.node_trips / kn), "leaf": int(sst.leaf_trips / kn),
-                                              "shade_passes": int(sst.shade_passes / kn), "waves": int(sst.waves / kn)},
+                                              "shade_passes": int(sst.shade_passes / kn), "waves": int(sst.waves / kn),
+                                              "background_waves": int(sst.background_waves / kn)},
                     "lane_utilisation": {"node": round(sst.node_visits / (64.0 * sst.node_trips), 3),
                                          "leaf": round(sst.tri_tests / (64.0 * sst.leaf_trips), 3),
                                          "shade": round(sst.rays / (64.0 * sst.shade_passes), 3)},
                     # the other candidate roofs, as fractions of their peaks (rocprofv3 PMC passes of this kernel at this shape,
                     # profiles/r02_pmc_fused_monkey_d64.txt; static -- a counter pass cannot run inside the bench):
                     "roofs": {"valu_issue": round(frac, 4), "l1_texture_addresser_busy": 0.83, "l1_data_return_busy": 0.97,
-                              "hbm_counter_bytes": 0.089, "lds_busy": 0.06,
-                              "source": "valu_issue live (exact trip counters x fitted per-trip cost); the others from profiles/r02_pmc_fused_monkey_d64.txt"},
+                              "hbm_counter_bytes": (round(traffic["hbm_bytes_per_launch"] / traffic["frames_per_launch"] * Fl / (kernel_us * 1e-6) / (HBM_PEAK_GBS * 1e9), 4)
+                                                    if traffic and traffic.get("hbm_bytes_per_launch") else None),
+                              "lds_busy": 0.06,
+                              "source": "valu_issue live (exact trip counters x fitted per-trip cost); hbm_counter_bytes = the PMC bytes of "
+                                        "roofline.traffic over this run's kernel time and 8 TB/s; TA / TD / LDS busy from profiles/r02_pmc_fused_monkey_d64.txt"},
                     "depth1_kernel_us": round(k1ms / k1n * 1e3, 2) if k1n else None,
                     "algorithmic_bytes_per_launch": int(bytes_per_launch),
                     "algorithmic_GBps_not_a_roof": round(bytes_per_launch / (kernel_us * 1e-6) / 1e9, 1),

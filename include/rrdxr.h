@@ -107,6 +107,8 @@ typedef struct rr_stats {
     uint64_t leaf_trips;
     uint64_t shade_passes;
     uint64_t waves;               /* waves that rendered (one 8x8 pixel block each in the block-per-wave kernels) */
+    uint64_t background_waves;    /* of those, the waves of blocks outside the scene's screen rectangle: RayGen + one Miss
+                                     (counted in shade_passes too), on a branch of their own in k_render_fused */
 } rr_stats;
 
 typedef struct rr_ray {

@@ -57,7 +57,7 @@ class Stats(C.Structure):
                 ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("pixels", C.c_uint64),
                 ("stats_valid", C.c_uint32), ("traversal_overflow", C.c_uint32), ("bvh_depth", C.c_uint32),
                 ("render_kernel", C.c_uint32), ("node_trips", C.c_uint64), ("leaf_trips", C.c_uint64),
-                ("shade_passes", C.c_uint64), ("waves", C.c_uint64)]
+                ("shade_passes", C.c_uint64), ("waves", C.c_uint64), ("background_waves", C.c_uint64)]
 
 
 # every symbol include/rrdxr.h declares: name -> (restype, argtypes)

@@ -74,6 +74,7 @@ struct MeshRes {
 // device block zeroed before every dispatch: counters, ray shards, error flag
 struct CounterBlock {
     unsigned long long counters[16];
+    static_assert(C_COUNT <= 16, "CounterBlock::counters holds every rr::Counter");
     uint32_t shards[RAY_SHARDS];
     uint32_t error;
     uint32_t pad[3];
@@ -1487,7 +1488,7 @@ int rr_get_stats(rr_context* ctx, rr_stats* out)
         out->hits = h->counters[C_HITS]; out->misses = h->counters[C_MISSES]; out->terminal_hits = h->counters[C_TERMINAL];
         out->tir = h->counters[C_TIR]; out->node_visits = h->counters[C_NODES]; out->tri_tests = h->counters[C_TRIS];
         out->node_trips = h->counters[C_NODE_TRIPS]; out->leaf_trips = h->counters[C_LEAF_TRIPS];
-        out->shade_passes = h->counters[C_PASSES]; out->waves = h->counters[C_WAVES];
+        out->shade_passes = h->counters[C_PASSES]; out->waves = h->counters[C_WAVES]; out->background_waves = h->counters[C_BG_WAVES];
     }
     out->traversal_overflow = h->error;
     out->bvh_depth = scene_stack_need(ctx);

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256, WPS ? WPS : TLAS ? RR_TLAS_WAVES_PER_SIMD(STAC
 
     LaneStats st;
     st.blocks = bp.tile_ok ? 1u : 0u;
+    if (STATS && bp.tile_ok && !(DIAG || (bp.x0 + 8u > a.hx0 && bp.x0 < a.hx1 && bp.y0 + 8u > a.hy0 && bp.y0 < a.hy1))) st.bg_blocks = 1u;
     if (valid) {
         st.pixels = 1;
         const bool may_hit = DIAG || (bp.x0 + 8u > a.hx0 && bp.x0 < a.hx1 && bp.y0 + 8u > a.hy0 && bp.y0 < a.hy1);

@@ -54,6 +54,7 @@ struct LaneStats {
     uint32_t rays = 0, hits = 0, miss = 0, term = 0, tir = 0, pixels = 0;
     uint32_t passes = 0;            // wave-level shading passes (ray rounds), STATS builds
     uint32_t blocks = 0;            // 8x8 pixel blocks this wave rendered (wave-uniform)
+    uint32_t bg_blocks = 0;         // of those, background blocks rendered on the RayGen + Miss branch (wave-uniform)
     TravCounters cnt = { 0, 0 };
 };
 
@@ -237,6 +238,7 @@ __device__ __forceinline__ void flush_stats(const DispatchDev& a, const LaneStat
         v = wave_reduce_add(st.cnt.leaf_trips); if (lane == 0 && v) atomicAdd(&a.counters[C_LEAF_TRIPS], (unsigned long long)v);
         v = wave_reduce_add(st.passes); if (lane == 0 && v) atomicAdd(&a.counters[C_PASSES], (unsigned long long)v);
         if (lane == 0 && st.blocks) atomicAdd(&a.counters[C_WAVES], (unsigned long long)st.blocks);
+        if (lane == 0 && st.bg_blocks) atomicAdd(&a.counters[C_BG_WAVES], (unsigned long long)st.bg_blocks);
     }
 }
 

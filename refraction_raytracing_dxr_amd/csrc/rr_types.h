@@ -171,6 +171,7 @@ constexpr uint32_t LDS_TICKET_WORDS = (2 * LDS_QUEUES + 1) * 16;
 enum Counter : int {
     C_RAYS = 0, C_PRIMARY, C_SECONDARY, C_HITS, C_MISSES, C_TERMINAL, C_TIR, C_NODES, C_TRIS,
     C_NODE_TRIPS, C_LEAF_TRIPS, C_PASSES, C_WAVES,      // wave-level loop trips of the STATS builds (what the vector unit issues for)
+    C_BG_WAVES,                                         // waves of background blocks (k_render_fused's RayGen + Miss branch)
     C_COUNT
 };
 constexpr int RAY_SHARDS = 1024;

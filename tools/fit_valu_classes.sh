@@ -27,5 +27,7 @@ monkey.obj 2 2
 sphere.obj 4 2
 shell.obj 5 2
 cube.obj 8 2
+sphere.obj 0 0
+ott.obj 8 2
 LIST
 cat $out/pmc_classes.txt

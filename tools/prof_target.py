@@ -29,7 +29,7 @@ st = r.stats()
 if stats:
     print(json.dumps({"workload": "%s %d/%d D%d x%d %dx%d" % (mesh, refr, refl, depth, launches, W, H), "launches": launches,
                       **{k: int(getattr(st, k)) for k in ("rays", "hits", "misses", "node_visits", "tri_tests", "node_trips", "leaf_trips",
-                                                         "shade_passes", "waves", "pixels")}}), flush=True)
+                                                         "shade_passes", "waves", "background_waves", "pixels")}}), flush=True)
 else:
     print("rays", st.rays, flush=True)
 r.close()
