@@ -350,10 +350,10 @@ def main():
                                          "shade": round(sst.rays / (64.0 * sst.shade_passes), 3)},
                     # the other candidate roofs, as fractions of their peaks (rocprofv3 PMC passes of this kernel at this shape,
                     # profiles/r02_pmc_fused_monkey_d64.txt; static -- a counter pass cannot run inside the bench):
-                    "roofs": {"valu_issue": round(frac, 4), "l1_texture_addresser_busy": 0.83, "l1_data_return_busy": 0.97,
+                    "roofs": {"valu_issue": round(frac, 4), "l1_texture_addresser_busy": 0.84, "l1_data_return_busy": 0.98,
                               "hbm_counter_bytes": (round(traffic["hbm_bytes_per_launch"] / traffic["frames_per_launch"] * Fl / (kernel_us * 1e-6) / (HBM_PEAK_GBS * 1e9), 4)
                                                     if traffic and traffic.get("hbm_bytes_per_launch") else None),
-                              "lds_busy": 0.06,
+                              "lds_busy": 0.03,
                               "source": "valu_issue live (exact trip counters x fitted per-trip cost); hbm_counter_bytes = the PMC bytes of "
                                         "roofline.traffic over this run's kernel time and 8 TB/s; TA / TD / LDS busy from profiles/r02_pmc_fused_monkey_d64.txt"},
                     "depth1_kernel_us": round(k1ms / k1n * 1e3, 2) if k1n else None,
