@@ -284,6 +284,20 @@ def main():
         total_rays = int(t[1])
         overflow = int(t[2])
 
+    # ---- N > 1: the run validates itself -- the last frame the pipeline assembled on rank 0 against the same frame rendered
+    # by rank 0 alone (untimed).  The kernels are deterministic, so anything but byte equality is a bug in the sharding, the
+    # gather or the de-interleave.
+    multi_gpu_check = None
+    if (world > 1 or force_sharded) and rank == 0 and not args.rotate_root:
+        got = sf.frames_host()[-1].copy()
+        r.set_tile_partition(0, 1)
+        ang = np.float32(0.01)
+        for _ in range(K - 1):                       # the frame loop's own arithmetic: angle += 0.01f in fp32 (RefractionDemo.cpp:567)
+            ang = np.float32(ang + np.float32(0.01))
+        r.render_orbit(W, H, 1, angle=float(ang), params=params, frames_per_dispatch=1)
+        want = r.read_frame()
+        multi_gpu_check = {"frame": K - 1, "identical_to_single_gpu_render": bool(np.array_equal(got, want)),
+                           "differing_pixels": int((got != want).any(axis=-1).sum())}
     # ---- roofline of the dominant kernel (k_render_fused), rank 0, single-GPU geometry ---------------------
     roofline = None
     cpu = None
@@ -417,6 +431,7 @@ def main():
                 "note": "render_only: each rank's tiles of the same frames, same launches and lanes, no gather, no de-interleave "
                         "(untimed extra pass).  end_to_end - max(render_only) = rank 0's gather ingest + assemble that the pipeline "
                         "did not hide"},
+            "multi_gpu_check": multi_gpu_check,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "monkey_16k": subdiv,

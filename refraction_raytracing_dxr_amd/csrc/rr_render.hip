@@ -582,6 +582,9 @@ static hipError_t launch_fused_s16(const SceneDev& sc, const DispatchDev& a, boo
 // SIMD, and the build for seven (72 registers, 64 words through scratch) is the fastest -- the 1 024-monkey grid at 2160p,
 // Depth 16: 7.51 ms per frame with 32-bit stacks (five waves), 7.23 / 6.95 / 7.24 ms built for six / seven / eight.
 // (Parking the reflected rays in LDS instead of registers -- 96 registers, five waves, a third of the spills -- measured 7.76.)
+// Trees of 31..39 levels (C4: ott.obj under a TLAS) get the 39-entry build for five waves: 934 us per frame at Depth 16
+// against 979 on 32-bit stacks (four waves), 993 / 1 051 built for six / seven; launches of one or two slices stay on the
+// 32-bit build (2.14 against 2.44 ms).
 template <int STACK, int WPS>
 static hipError_t launch_fused_tlas16(const SceneDev& sc, const DispatchDev& a, bool stats, hipStream_t s)
 {
@@ -595,6 +598,7 @@ hipError_t launch_render_fused(const SceneDev& sc, const DispatchDev& a, int sta
 {
     if (a.n_blocks == 0) return hipSuccess;
     if (stack16 && !a.diag && !sc.single_identity && pend <= 2 && stack <= 30) return launch_fused_tlas16<30, 7>(sc, a, stats, s);
+    if (stack16 && !a.diag && !sc.single_identity && pend <= 2 && stack <= 39) return launch_fused_tlas16<39, 5>(sc, a, stats, s);
     if (stack16 && !a.diag && sc.single_identity && stack <= 39)
         return pend <= 2 ? launch_fused_s16<2>(sc, a, stats, s) : launch_fused_s16<8>(sc, a, stats, s);
     if (a.diag) {       // diagnostic build of the reference-scene kernel (RR_DEBUG_DIAG; never used by the product path)
