@@ -164,6 +164,7 @@ struct rr_context {
     int  dbg_ticket_blocks = 0;      // RR_DEBUG_TICKET: 1 = k_render_lds treats the whole frame as the mesh rectangle, 2 = no rectangle
     uint32_t dbg_async[2] = { 2, 2 };    // RR_DEBUG_ASYNC="leaf,shade": thresholds of k_render_scene_async in eighths (rr_types.h)
     bool dbg_tile_order = true;      // RR_DEBUG_TILE_ORDER=0: tiles in image order (DispatchDev::rt_*)
+    int  dbg_stream_waves = 7;       // RR_DEBUG_STREAM_WAVES: waves per SIMD k_render_scene_stream is built for (5..7)
     bool dbg_tlas32 = false;         // RR_DEBUG_TLAS32: two-level scenes keep 32-bit stack entries and register-parked rays
     int  dbg_shape = 0;              // RR_DEBUG_SHAPE: first k_render_lds workgroup shape to consider (rr_launch.h)
     std::string dbg_diag;            // RR_DEBUG_DIAG: file that receives per-wave diagnostics of Depth-1 dispatches
@@ -362,11 +363,12 @@ int rr_create(int device_ordinal, rr_context** out)
     (void)hipMemsetAsync(ctx->d_cnt, 0, sizeof(CounterBlock), ctx->stream);
     (void)hipMemsetAsync(ctx->d_tickets, 0, (rr_context::MAX_LANES + 1) * LDS_TICKET_WORDS * sizeof(uint32_t), ctx->stream);   // the kernel leaves them zero
     if (const char* e = getenv("RR_DEBUG_KERNEL"))
-        ctx->dbg_kernel = !strcmp(e, "fused") ? 1 : !strcmp(e, "async") ? 2 : !strcmp(e, "wavefront") ? 3 : !strcmp(e, "lds") ? 4 : !strcmp(e, "paths") ? 5 : !strcmp(e, "refill") ? 6 : !strcmp(e, "scene-async") ? 8 : 0;
+        ctx->dbg_kernel = !strcmp(e, "fused") ? 1 : !strcmp(e, "async") ? 2 : !strcmp(e, "wavefront") ? 3 : !strcmp(e, "lds") ? 4 : !strcmp(e, "paths") ? 5 : !strcmp(e, "refill") ? 6 : !strcmp(e, "scene-async") ? 8 : !strcmp(e, "scene-stream") ? 9 : 0;
     if (const char* e = getenv("RR_DEBUG_STACK")) ctx->dbg_stack = atoi(e);
     if (const char* e = getenv("RR_DEBUG_TICKET")) ctx->dbg_ticket_blocks = atoi(e);
     if (const char* e = getenv("RR_DEBUG_SHAPE")) ctx->dbg_shape = atoi(e);
     if (const char* e = getenv("RR_DEBUG_TLAS32")) ctx->dbg_tlas32 = atoi(e) != 0;
+    if (const char* e = getenv("RR_DEBUG_STREAM_WAVES")) ctx->dbg_stream_waves = atoi(e);
     if (const char* e = getenv("RR_DEBUG_TILE_ORDER")) ctx->dbg_tile_order = atoi(e) != 0;
     if (const char* e = getenv("RR_DEBUG_ASYNC")) { unsigned l = 2, sh = 2; if (sscanf(e, "%u,%u", &l, &sh) == 2 && l >= 1 && sh >= 1) { ctx->dbg_async[0] = l; ctx->dbg_async[1] = sh; } }
     if (const char* e = getenv("RR_DEBUG_DIAG")) ctx->dbg_diag = e;
@@ -939,6 +941,8 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     const bool refill_stack16 = ctx->single_identity ? (m0 && m0->n_tris < 32768u && need > 19)
                                                      : (pool_nodes < 32768u && ctx->n_pool_tris + ctx->n_insts < 32768u);
     // (experiment, RR_DEBUG_KERNEL=scene-async: the lane-asynchronous kernel for scenes with a TLAS, see rr_render_exp.hip)
+    const bool scene_stream = ctx->dbg_kernel == 9 && !ctx->single_identity && p.max_reflect <= 2 && need <= 30 && refill_stack16 && !compact && !a.diag &&
+                              ctx->dbg_stack == 0 && !paths_kernel;
     const bool scene_async = ctx->dbg_kernel == 8 && !ctx->single_identity && p.max_reflect <= 2 && need <= 39 && !a.diag && ctx->dbg_stack == 0 && !paths_kernel;
     // (experiment, RR_DEBUG_KERNEL=refill: on the 1 024-monkey grid it raises the share of live lanes per shading pass from
     // 54 % to 80 % and the frame time from 8.9 to 10.8 ms -- a pass lasts as long as its longest ray either way, and with
@@ -948,6 +952,8 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     if (wavefront) RR_HIP(launch_render_wavefront(sc, a, ctx->wf, stack_sel, ctx->stream));
     else if (refill_kernel) RR_HIP(launch_render_refill(sc, a, (int)need, stats, ctx->stream, refill_stack16));
     else if (scene_async) RR_HIP(launch_render_scene_async(sc, a, (int)need, stats, ctx->stream, refill_stack16));
+    else if (scene_stream) RR_HIP(launch_render_scene_stream(sc, a, ctx->d_tickets + (size_t)rr_context::MAX_LANES * LDS_TICKET_WORDS, ctx->n_cus,
+                                                             ctx->dbg_stream_waves, stats, ctx->stream));
     else if (ctx->dbg_kernel == 2 && ctx->single_identity) RR_HIP(launch_render_async(sc, a, stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream));
     else
 #endif
@@ -1007,7 +1013,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         (void)hipFree(d_diag);
         if (FILE* f = fopen(diag_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
-    ctx->last_kernel = wavefront ? 3u : paths_kernel ? 2u : refill_kernel ? 4u : scene_async ? 5u : lds_kernel ? 1u : 0u;
+    ctx->last_kernel = wavefront ? 3u : paths_kernel ? 2u : refill_kernel ? 4u : scene_async ? 5u : scene_stream ? 6u : lds_kernel ? 1u : 0u;
     ctx->W = width; ctx->H = height; ctx->frame_world = ctx->tile_world; ctx->frame_depth = depth;
     ctx->have_f32 = want_f32; ctx->have_frame = ext_tiles == nullptr; ctx->have_assembled = false;
     if (!ext_tiles) ctx->frame_base = out_base;

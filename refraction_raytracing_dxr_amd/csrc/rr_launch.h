@@ -52,6 +52,8 @@ hipError_t launch_render_async(const SceneDev& sc, const DispatchDev& a, int sta
 hipError_t launch_render_refill(const SceneDev& sc, const DispatchDev& a, int stack, bool stats, hipStream_t s, bool stack16);
 // scenes with a TLAS: lane-asynchronous renderer (k_render_scene_async)
 hipError_t launch_render_scene_async(const SceneDev& sc, const DispatchDev& a, int stack, bool stats, hipStream_t s, bool stack16);
+// the same as a streaming kernel (k_render_scene_stream): persistent waves, one ticket word for the launch
+hipError_t launch_render_scene_stream(const SceneDev& sc, const DispatchDev& a, uint32_t* ticket, int n_cus, int waves, bool stats, hipStream_t s);
 #endif
 
 // ---- rr_bvh_build.hip

@@ -690,6 +690,182 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_render_scene_async(Scen
 }
 
 
+// ---------------------------------------------------------------------------------------------------
+// The same lane-asynchronous renderer as a STREAMING kernel (RR_DEBUG_KERNEL=scene-stream): persistent waves that pull 8x8
+// pixel blocks from one ticket counter for the whole launch (numbered as k_render_fused's wave-blocks), a lane taking the next
+// pixel of the wave's current block as soon as its own is finished -- so a wave has no tail of its own, only the launch has
+// one --, parked rays in registers / scratch instead of LDS and the 30-entry 16-bit stacks, i.e. the LDS and register budget
+// of the seven-wave lock-step build, and several internal-node steps per vote.
+template <int STACK, bool STATS, class E, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_render_scene_stream(SceneDev sc, DispatchDev a, uint32_t* ticket)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    E* const stk = reinterpret_cast<E*>(lds) + wave * (STACK * 64) + lane;
+    RegPark<2> park;
+
+    constexpr int TRAV_FIN = (int)0x80000001;       // the lane's ray is finished: shade it
+    constexpr uint32_t NO_INST = 0xffffffffu;
+    const QNode* __restrict__ nodes = sc.pool_nodes;
+    const uint32_t total_blocks = a.n_blocks * 4u;  // wave-blocks of the launch
+
+    LaneStats st;
+    // the block the wave is handing out: its position, the pixels not yet taken
+    uint32_t res_left = 0, res_x0 = 0, res_y0 = 0, res_frame = 0;
+    bool res_may_hit = false, pool_empty = false;
+    bool alive = false;
+    uint32_t xy = 0, frame = 0;                     // the lane's pixel
+    RayState r;
+    r.O = r.D = mk3(0.0f, 0.0f, 0.0f); r.w = 0.0f; r.tmin = r.tmax = 0.0f; r.count = 0; r.outside = true;
+    f3 acc = mk3(0.0f, 0.0f, 0.0f);
+    int np = 0;
+    int node = TRAV_FIN;
+    E* top = stk;
+    const E* floor = stk;
+    uint32_t cur = NO_INST, cull = 0;
+    f3 Oc = r.O, Dc = r.D;
+    BoxRay br = box_ray(r.O, mk3(1.0f, 1.0f, 1.0f), sc.scale, sc.grid);
+    HitRec best;
+    best.t = 0.0f; best.hit = false; best.prim = 0; best.leaf = 0; best.inst = 0; best.U = best.V = 0.0f; best.ad = 1.0f;
+
+    auto start_ray = [&](bool traced) {
+        best.t = r.tmax; best.hit = false; best.prim = 0; best.leaf = 0; best.inst = 0; best.U = 0.0f; best.V = 0.0f; best.ad = 1.0f;
+        cull = r.outside ? CULL_BACK : CULL_FRONT;
+        cur = NO_INST; Oc = r.O; Dc = r.D; top = stk; floor = stk;
+        br = box_ray(r.O, r.D, sc.scale, sc.grid);
+        node = traced ? 0 : TRAV_FIN;
+    };
+
+    for (;;) {
+        // ---- lanes without a pixel take the next ones of the wave's block; an empty block is replaced from the pool
+        unsigned long long need = __ballot(!alive);
+        while (need != 0ull && !(pool_empty && res_left == 0u)) {
+            if (res_left == 0u) {
+                uint32_t t = 0;
+                if (lane == 0) t = atomicAdd(ticket, 1u);
+                t = __builtin_amdgcn_readfirstlane(t);
+                if (t >= total_blocks) { pool_empty = true; break; }
+                const BlockPos bp = wave_block_pos(a, t);
+                if (!bp.tile_ok) continue;
+                res_x0 = bp.x0; res_y0 = bp.y0; res_frame = bp.frame; res_left = 64u;
+                res_may_hit = bp.x0 + 8u > a.hx0 && bp.x0 < a.hx1 && bp.y0 + 8u > a.hy0 && bp.y0 < a.hy1;
+                if (STATS) st.blocks += 1u;
+            }
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            const uint32_t first = 64u - res_left;              // pixels of the block already handed out
+            if (!alive && rank < res_left) {
+                const uint32_t pix = first + rank;
+                const uint32_t x = res_x0 + compact1by1(pix), y = res_y0 + compact1by1(pix >> 1);
+                if (x < a.W && y < a.H) {
+                    xy = x | (y << 16); frame = res_frame;
+                    r = primary_ray(a, a.cams[res_frame], x, y);
+                    acc = mk3(0.0f, 0.0f, 0.0f); np = 0;
+                    alive = true;
+                    st.pixels += 1;
+                    start_ray(res_may_hit);
+                }
+            }
+            const uint32_t taken = (uint32_t)__popcll(need) < res_left ? (uint32_t)__popcll(need) : res_left;
+            res_left -= taken;
+            need = __ballot(!alive);
+            if (res_left != 0u) break;              // lanes still without a pixel got an off-screen one: they ask again next trip
+        }
+        const unsigned long long m_alive = __ballot(alive);
+        if (m_alive == 0ull) { if (pool_empty && res_left == 0u) break; else continue; }
+        const unsigned long long m_fin = __ballot(alive && node == TRAV_FIN);
+        const unsigned long long m_node = __ballot(alive && node >= 0);
+        const unsigned long long m_leaf = m_alive & ~m_fin & ~m_node;
+        const int n_alive = __popcll(m_alive), n_fin = __popcll(m_fin), n_node = __popcll(m_node), n_leaf = __popcll(m_leaf);
+        const int n_trav = n_node + n_leaf;
+        if (n_fin > 0 && (n_trav == 0 || n_fin * 8 >= n_alive * (int)a.async_shade_num)) {
+            if (alive && node == TRAV_FIN) {
+                if (best.hit) {
+                    const InstDev& in = sc.insts[best.inst];
+                    f3 Oh = r.O, Dh = r.D;
+                    if (!in.identity) { Oh = xform_point(in.inv, r.O); Dh = xform_dir(in.inv, r.D); }
+                    hit_attributes(sc.pool_tris, Oh, Dh, best);
+                }
+                ++st.rays;
+                if (STATS && first_active_lane()) ++st.passes;
+                if (shade_ray<STATS, true>(sc, a, best, r, acc, np, park, st)) {
+                    start_ray(true);
+                } else {
+                    const uint32_t x = xy & 0xffffu, y = xy >> 16;
+                    store_pixel(a, a.out_rgba8 + (size_t)frame * a.frame_stride, a.out_f32 ? a.out_f32 + (size_t)frame * a.frame_stride : nullptr,
+                                (size_t)y * a.W + x, acc);
+                    alive = false;
+                }
+            }
+        } else if (n_node > 0 && n_leaf * 8 < n_trav * (int)a.async_leaf_num) {
+            // internal-node steps, until the lanes holding a leaf (or the end of a subtree) reach the share at which the leaf step runs
+            if (alive && node >= 0) {
+                const int stop = (n_trav * (8 - (int)a.async_leaf_num) + 7) / 8;       // lanes at internal nodes below which the vote changes
+                do {
+                    const NodeQ q = load_node(nodes, node);
+                    if (STATS) { st.cnt.nodes++; if (first_active_lane()) st.cnt.node_trips++; }
+                    node = node_step(br, q, r.tmin, best.t, top, floor);
+                } while (node >= 0 && __popcll(__ballot(1)) > stop);
+            }
+        } else {
+            if (alive && node < 0 && node != TRAV_FIN) {    // leaf step
+                if (STATS && first_active_lane()) st.cnt.leaf_trips++;
+                if (node == TRAV_DONE) {
+                    if (cur == NO_INST) node = TRAV_FIN;
+                    else {
+                        cur = NO_INST; Oc = r.O; Dc = r.D; cull = r.outside ? CULL_BACK : CULL_FRONT; floor = stk;
+                        br = box_ray(r.O, r.D, sc.scale, sc.grid);
+                        if (top > stk) { top -= STACK_STRIDE; node = StackCodec<E>::dec(*top); } else node = TRAV_FIN;
+                    }
+                } else {
+                    const uint32_t L = (uint32_t)~node;
+                    if (L < sc.n_pool_tris) {
+                        if (STATS) st.cnt.tris++;
+                        tri_test(sc.pool_tris, L, Oc, Dc, r.tmin, cull, cur, best);
+                        if (top > floor) { top -= STACK_STRIDE; node = StackCodec<E>::dec(*top); } else node = TRAV_DONE;
+                    } else {
+                        const uint32_t ii = L - sc.n_pool_tris;
+                        const InstDev& in = sc.insts[ii];
+                        if (in.mask & 0xffu) {
+                            uint32_t f = r.outside ? CULL_BACK : CULL_FRONT;
+                            if (in.flags & 0x1u) f &= ~(CULL_BACK | CULL_FRONT);
+                            else if (in.flags & 0x2u) {
+                                if (f & CULL_BACK) f = (f & ~CULL_BACK) | CULL_FRONT;
+                                else if (f & CULL_FRONT) f = (f & ~CULL_FRONT) | CULL_BACK;
+                            }
+                            cull = f; cur = ii; floor = top;
+                            if (!in.identity) { Oc = xform_point(in.inv, r.O); Dc = xform_dir(in.inv, r.D); }
+                            br = box_ray(Oc, Dc, in.scale, in.grid);
+                            node = (int)in.root;
+                        } else if (top > stk) { top -= STACK_STRIDE; node = StackCodec<E>::dec(*top); } else node = TRAV_DONE;
+                    }
+                }
+            }
+        }
+    }
+    flush_stats<STATS>(a, st, blockIdx.x * 4u + wave, lane);
+}
+
+template <int STACK, class E, int WPS>
+static hipError_t launch_scene_stream_se(const SceneDev& sc, const DispatchDev& a, uint32_t* ticket, int n_cus, bool stats, hipStream_t s)
+{
+    const size_t lds = (size_t)4 * STACK * 64 * sizeof(E);
+    const dim3 grid((uint32_t)n_cus * WPS);
+    hipError_t e = hipMemsetAsync(ticket, 0, 4, s);
+    if (e != hipSuccess) return e;
+    if (stats) hipLaunchKernelGGL((k_render_scene_stream<STACK, true, E, WPS>), grid, dim3(256), lds, s, sc, a, ticket);
+    else       hipLaunchKernelGGL((k_render_scene_stream<STACK, false, E, WPS>), grid, dim3(256), lds, s, sc, a, ticket);
+    return hipGetLastError();
+}
+
+// scenes with a TLAS, unsharded raster frames, max_reflect <= 2, every stack entry fits 16 bits, trees of at most 30 levels
+hipError_t launch_render_scene_stream(const SceneDev& sc, const DispatchDev& a, uint32_t* ticket, int n_cus, int waves, bool stats, hipStream_t s)
+{
+    if (a.n_blocks == 0) return hipSuccess;
+    if (waves >= 7) return launch_scene_stream_se<30, uint16_t, 7>(sc, a, ticket, n_cus, stats, s);
+    if (waves == 6) return launch_scene_stream_se<30, uint16_t, 6>(sc, a, ticket, n_cus, stats, s);
+    return launch_scene_stream_se<30, uint16_t, 5>(sc, a, ticket, n_cus, stats, s);
+}
+
 template <int STACK, class E, int WPS>
 static hipError_t launch_scene_async_se(const SceneDev& sc, const DispatchDev& a, bool stats, hipStream_t s)
 {
