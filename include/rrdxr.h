@@ -82,6 +82,9 @@ typedef struct rr_dispatch_params {
 #define RR_DISPATCH_KEEP_COUNTERS 0x8u  /* do not zero the rr_get_stats counters first: keep accumulating */
 #define RR_DISPATCH_TILES_RGB8    0x10u /* rr_render_orbit_sharded only: tiles are written as 3 bytes per pixel (alpha is
                                          * always 255): a quarter less to gather; rr_assemble_frames_rgb8 restores RGBA8 */
+#define RR_DISPATCH_TONEMAP_REINHARD 0x20u /* SURVEY 8f.2, additive: the R8G8B8A8_UNORM store takes c / (1 + c) per channel (NaN and
+                                              negative -> 0, +inf -> 1) instead of the reference's saturating c; the float frame
+                                              (RR_DISPATCH_FLOAT_OUTPUT) stays linear.  Off by default = RayTracing.hlsl:62 */
 
 typedef struct rr_stats {
     uint64_t rays;                /* every TraceRay: primary + secondary */

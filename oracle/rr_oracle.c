@@ -128,6 +128,14 @@ uint8_t rro_unorm8(float x)
     return (uint8_t)floorf(x * 255.0f + 0.5f);
 }
 
+/* SURVEY 8f.2 tone map option (not in the reference): c / (1 + c); NaN and c <= 0 -> 0, +inf -> 1 */
+static float rro_reinhard(float x)
+{
+    if (!(x > 0.0f)) return 0.0f;
+    float xm = x < 3.4028234663852886e38f ? x : 3.4028234663852886e38f;
+    return xm / (1.0f + xm);
+}
+
 void rro_default_params(rro_params* p)
 {
     p->max_refract = 5;
@@ -140,6 +148,7 @@ void rro_default_params(rro_params* p)
     p->use_libm = 0;
     p->accum_mode = 0;
     p->use_bvh = 0;
+    p->tonemap = 0;
 }
 
 uint64_t rro_fnv1a64(const void* bytes, uint64_t n)
@@ -872,9 +881,11 @@ static void* worker(void* arg)
             size_t pix = (size_t)y * j->w + x;
             if (j->out_rgb) { j->out_rgb[pix * 3 + 0] = col.x; j->out_rgb[pix * 3 + 1] = col.y; j->out_rgb[pix * 3 + 2] = col.z; }
             if (j->out_rgba8) {                                        /* hlsl:62 float4(color,1) -> UNORM8 */
-                j->out_rgba8[pix * 4 + 0] = rro_unorm8(col.x);
-                j->out_rgba8[pix * 4 + 1] = rro_unorm8(col.y);
-                j->out_rgba8[pix * 4 + 2] = rro_unorm8(col.z);
+                v3 cq = col;
+                if (j->p->tonemap) { cq.x = rro_reinhard(col.x); cq.y = rro_reinhard(col.y); cq.z = rro_reinhard(col.z); }
+                j->out_rgba8[pix * 4 + 0] = rro_unorm8(cq.x);
+                j->out_rgba8[pix * 4 + 1] = rro_unorm8(cq.y);
+                j->out_rgba8[pix * 4 + 2] = rro_unorm8(cq.z);
                 j->out_rgba8[pix * 4 + 3] = 255;
             }
             if (j->out_raycount) j->out_raycount[pix] = (uint16_t)(c.pixel_rays > 65535 ? 65535 : c.pixel_rays);

@@ -54,6 +54,8 @@ typedef struct rro_params {
     int   use_libm;              /* 0: spec'd rr_atan2f/rr_acosf; 1: libm atan2f/acosf */
     int   accum_mode;            /* 0: literal recursive +=; 1: path-weight sum in DFS order */
     int   use_bvh;               /* 0: brute force over all triangles; 1: CPU median-split BVH */
+    int   tonemap;               /* 0: the reference's saturating UNORM8 store (hlsl:62); 1: c / (1 + c) first (SURVEY 8f.2,
+                                    the product's RR_DISPATCH_TONEMAP_REINHARD) */
 } rro_params;
 
 typedef struct rro_stats {

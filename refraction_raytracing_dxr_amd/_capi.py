@@ -16,6 +16,7 @@ DISPATCH_COLLECT_STATS = 0x2
 DISPATCH_TIME_KERNEL = 0x4
 DISPATCH_KEEP_COUNTERS = 0x8
 DISPATCH_TILES_RGB8 = 0x10
+DISPATCH_TONEMAP_REINHARD = 0x20
 BUILD_PREFER_FAST_TRACE = 0x4
 BUILD_PREFER_FAST_BUILD = 0x8
 RAY_FLAG_CULL_BACK = 0x10

@@ -849,6 +849,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     a.n_local_tiles = local;
     a.n_blocks = a.blocks_per_frame * depth;
     a.compact_out = compact ? (rgb8 ? 2u : 1u) : 0u;
+    a.tonemap = (p.flags & RR_DISPATCH_TONEMAP_REINHARD) ? 1u : 0u;
     a.max_refract = p.max_refract; a.max_reflect = p.max_reflect;
     a.ior = p.ior; a.inv_ior = 1.0f / p.ior;
     a.tmin_p = p.tmin_primary; a.tmax_p = p.tmax_primary; a.tmin_s = p.tmin_secondary; a.tmax_s = p.tmax_secondary;

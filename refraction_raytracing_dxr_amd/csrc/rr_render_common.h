@@ -209,7 +209,12 @@ __device__ __forceinline__ f3 render_pixel(const SceneDev& sc, const DispatchDev
 // RenderTarget[xy] = float4(color,1) -> R8G8B8A8_UNORM (hlsl:62); o: element index inside the slice
 __device__ __forceinline__ void store_pixel(const DispatchDev& a, uint32_t* out_rgba8, float4* out_f32, size_t o, f3 acc)
 {
-    const uint32_t packed = unorm8(acc.x) | (unorm8(acc.y) << 8) | (unorm8(acc.z) << 16) | 0xff000000u;
+    f3 c = acc;
+    if (a.tonemap) {            // c / (1 + c) with c clamped to the largest finite float (so that +inf gives 1); NaN and c <= 0 end as 0 in unorm8
+        c = mk3(fminf(acc.x, 3.4028234663852886e38f), fminf(acc.y, 3.4028234663852886e38f), fminf(acc.z, 3.4028234663852886e38f));
+        c = mk3(acc.x > 0.0f ? c.x / (1.0f + c.x) : 0.0f, acc.y > 0.0f ? c.y / (1.0f + c.y) : 0.0f, acc.z > 0.0f ? c.z / (1.0f + c.z) : 0.0f);
+    }
+    const uint32_t packed = unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | 0xff000000u;
     if (a.compact_out == 2u) {               // RGB8 tiles for the gather: alpha is always 255, not worth a link byte
         uint8_t* p3 = reinterpret_cast<uint8_t*>(out_rgba8) + o * 3;
         p3[0] = (uint8_t)packed; p3[1] = (uint8_t)(packed >> 8); p3[2] = (uint8_t)(packed >> 16);

@@ -112,6 +112,7 @@ struct DispatchDev {
     uint32_t n_local_tiles;         // tiles this rank renders
     uint32_t n_blocks;              // 4 blocks (32x8 strips) per local tile, tiles rounded up to a multiple of 8
     uint32_t compact_out;           // 0: W*H raster; 1: [local tile][32*32] RGBA8 (sharded frames); 2: the same as RGB8, 3 B/px
+    uint32_t tonemap;               // RR_DISPATCH_TONEMAP_REINHARD: the UNORM8 store takes c / (1 + c)
     int32_t max_refract, max_reflect;
     float ior, inv_ior;
     float tmin_p, tmax_p, tmin_s, tmax_s;

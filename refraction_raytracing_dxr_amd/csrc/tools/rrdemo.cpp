@@ -69,6 +69,7 @@ int main(int argc, char** argv)
         else if (arg("--frames-per-gather")) fpg = atoi(argv[++i]);
         else if (arg("--rank")) rank = atoi(argv[++i]);
         else if (arg("--id-file")) idfile = argv[++i];
+        else if (!strcmp(argv[i], "--tonemap")) opt.dispatch.flags |= RR_DISPATCH_TONEMAP_REINHARD;      // c / (1 + c) before the UNORM8 store
         else if (arg("--max-refract")) opt.dispatch.max_refract = atoi(argv[++i]);
         else if (arg("--max-reflect")) opt.dispatch.max_reflect = atoi(argv[++i]);
         else if (arg("--size")) { if (sscanf(argv[++i], "%dx%d", &opt.width, &opt.height) != 2) { fprintf(stderr, "bad --size\n"); return 2; } }

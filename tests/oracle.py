@@ -30,7 +30,7 @@ class Params(C.Structure):
     _fields_ = [("max_refract", C.c_int), ("max_reflect", C.c_int), ("ior", C.c_float),
                 ("tmin_primary", C.c_float), ("tmax_primary", C.c_float),
                 ("tmin_secondary", C.c_float), ("tmax_secondary", C.c_float),
-                ("use_libm", C.c_int), ("accum_mode", C.c_int), ("use_bvh", C.c_int)]
+                ("use_libm", C.c_int), ("accum_mode", C.c_int), ("use_bvh", C.c_int), ("tonemap", C.c_int)]
 
 
 class Stats(C.Structure):

@@ -254,6 +254,27 @@ def test_out_of_range_texel_through_dispatch_rays(gpu):
         assert rgba[0, 0, 0] == (0 if expect == 0.0 else 191)
 
 
+def test_tonemapped_frame_matches_the_oracle(gpu):
+    """RR_DISPATCH_TONEMAP_REINHARD on a real frame: monkey.obj under the bench's HDR env map (texels up to 16, most of them
+    saturate the plain store), RGBA8 identical to the oracle's tone-mapped store, float frame identical to the plain run."""
+    m = load("monkey.obj")
+    env = procedural_env(256, 128, seed=0)
+    assert env.max() > 4.0
+    gpu_scene(gpu, [m], env)
+    s = oracle_scene([m], env)
+    sc = rr.camera_orbit(0.2)
+    gpu.set_camera(sc)
+    W, H = 160, 100
+    out = {}
+    for tm in (0, 1):
+        gpu.dispatch_rays(W, H, rr.default_params(max_refract=8, flags=rr.DISPATCH_FLOAT_OUTPUT | (rr.DISPATCH_TONEMAP_REINHARD if tm else 0)))
+        out[tm] = gpu.read_frame(want_float=True)
+        ref = s.render(np.array(sc.proj_inv, np.float32), np.array(sc.camera_loc, np.float32), W, H, O.default_params(use_bvh=1, max_refract=8, accum_mode=1, tonemap=tm))
+        assert np.array_equal(out[tm][0], ref["rgba8"]), tm
+    assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+    assert (out[0][0][..., :3] == 255).mean() > 0.3 and (out[1][0][..., :3] == 255).mean() < 0.01      # the plain store saturates, the tone map does not
+
+
 def test_unorm8_store_edges_through_dispatch_rays(gpu):
     """The typed UAV store to R8G8B8A8_UNORM (RefractionDemo.cpp:431; hlsl:62): NaN -> 0, below 0 -> 0, from 1 up -> 255,
     floor(x * 255 + 0.5) in between -- a frame of Misses over an env map whose texels ARE the edge values (the kernel's
@@ -283,6 +304,18 @@ def test_unorm8_store_edges_through_dispatch_rays(gpu):
     assert np.array_equal(rgba[..., :3], want) and (rgba[..., 3] == 255).all()
     seen = set(np.unique(rgba[..., :3]))
     assert {0, 1, 127, 128, 254, 255} <= seen                     # the frame really visits the edges
+    # the tone-map option (RR_DISPATCH_TONEMAP_REINHARD): c / (1 + c) in front of the same store; the float frame stays linear
+    gpu.dispatch_rays(W, H, rr.default_params(flags=rr.DISPATCH_FLOAT_OUTPUT | rr.DISPATCH_TONEMAP_REINHARD))
+    rgba_t, f32_t = gpu.read_frame(want_float=True)
+    ref_t = s.render(np.array(sc.proj_inv, np.float32), np.array(sc.camera_loc, np.float32), W, H, O.default_params(use_bvh=1, accum_mode=1, tonemap=1))
+    assert np.array_equal(rgba_t, ref_t["rgba8"])
+    assert np.array_equal(f32_t.view(np.uint32), f32.view(np.uint32))
+    with np.errstate(invalid="ignore", over="ignore", divide="ignore"):
+        xm = np.minimum(x, np.float32(3.4028234663852886e38))
+        t = np.where(x > 0, xm / (np.float32(1.0) + xm), np.float32(0.0)).astype(np.float32)
+        want_t = np.where(~(t > 0), 0, np.where(t >= 1, 255, np.floor(t * np.float32(255.0) + np.float32(0.5)))).astype(np.uint8)
+    assert np.array_equal(rgba_t[..., :3], want_t)
+    assert rgba_t[..., :3].max() == 255 and (rgba_t[..., :3][np.isinf(x) & (x > 0)] == 255).all()      # +inf -> 1
 
 
 @pytest.mark.skipif(not experimental_build(), reason="the product library does not contain the experiments (build with RR_EXPERIMENTAL=1)")

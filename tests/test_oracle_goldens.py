@@ -254,3 +254,23 @@ def test_committed_golden_frames_are_reproduced():
         assert np.array_equal(rgba, gold[key + "_rgba8"]), name
         assert np.array_equal(rgb.view(np.uint32), gold[key + "_rgb"].view(np.uint32)), name
         assert np.array_equal(cnt, gold[key + "_counts"]), name
+
+
+def test_oracle_tonemap_option_is_c_over_one_plus_c():
+    """the tone-map option of the checker itself (the product's RR_DISPATCH_TONEMAP_REINHARD is tested against
+    it on the GPU): the float image is untouched, RGBA8 = unorm8(c / (1 + c))."""
+    import numpy as np
+    m_v, m_i = O.mesh_load(O.asset("cube.obj"))
+    s = O.Scene()
+    s.add_mesh(m_v, m_i)
+    rng = np.random.default_rng(3)
+    env = (rng.random((16, 32, 3)).astype(np.float32) * np.float32(12.0))
+    s.set_envmap(env)
+    M, cam = O.camera(0.3)
+    a = s.render(M, cam, 48, 32, O.default_params(use_bvh=1))
+    b = s.render(M, cam, 48, 32, O.default_params(use_bvh=1, tonemap=1))
+    assert np.array_equal(a["rgb"], b["rgb"])
+    x = a["rgb"].astype(np.float32)
+    t = np.where(x > 0, x / (np.float32(1.0) + x), np.float32(0.0)).astype(np.float32)
+    want = np.where(~(t > 0), 0, np.where(t >= 1, 255, np.floor(t * np.float32(255.0) + np.float32(0.5)))).astype(np.uint8)
+    assert np.array_equal(b["rgba8"][..., :3], want) and not np.array_equal(a["rgba8"], b["rgba8"])
