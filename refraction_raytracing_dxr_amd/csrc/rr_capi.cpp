@@ -1363,7 +1363,7 @@ struct Rccl {
         ok = GetUniqueId && CommInitRank && CommDestroy && GroupStart && GroupEnd && Send && Recv;
     }
 };
-const Rccl& rccl() { static const Rccl r; return r; }
+extern "C++" const Rccl& rccl() { static const Rccl r; return r; }      // (this translation unit's tail is inside extern "C")
 static_assert(sizeof(ncclUniqueId) == 128, "rr_comm_unique_id hands out 128 bytes");
 } // namespace
 
