@@ -996,9 +996,9 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
                        ctx->meshes[(size_t)ctx->inst_host[0].blas].n_tris < 32768u;
         // two-level scenes: 16-bit entries wherever every node / leaf reference of the pool fits them (RR_DEBUG_TLAS32=1: never)
         if (!ctx->single_identity && refill_stack16 && (need <= 30 || (need <= 39 && depth > 2)) && p.max_reflect <= 2 && ctx->dbg_stack == 0 && !ctx->dbg_tlas32) stack16 = true;
-        // one or two slices per launch: the tail of a few long waves sets the time, and those run faster without the
-        // spills of the 6..8-wave builds (monkey Depth 1: 446 us with the 5-wave build, 475 with the 8-wave one)
-        if (depth <= 2 && ctx->single_identity && stack_sel < 31 && ctx->dbg_stack == 0) { stack_sel = 31; stack16 = false; }
+        // (launches of one or two slices used to take the five-wave build, whose long waves ran faster without the spills of the
+        // 6..8-wave builds; since the background branch left those builds with six spilled words the ladder above is the faster one
+        // at every depth: sphere.obj Depth 1 250 us against 268, monkey.obj and shell.obj equal)
         if (depth <= 2 && ctx->single_identity) stack16 = false;
         // (the two-level 16-bit-stack builds are sized by the tree itself: 30 entries still leave five workgroups per CU)
         RR_HIP(launch_render_fused(sc, a, !ctx->single_identity && stack16 && ctx->dbg_stack == 0 ? (int)need : stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream, stack16));
