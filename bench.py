@@ -250,6 +250,9 @@ def main():
         # a rank's share of a launch has 1/world of the blocks: keep launches long enough for their tails not to show
         # (tools/exp_lanes.py, world 8: 113 us/frame-equivalent at 64 frames per launch, 108 at 256)
         Fn = args.frames_per_dispatch * max(1, min(world // 2, 4))
+        # a run shorter than two such batches is split in two, so that the gather of the first half travels under the render of
+        # the second and the de-interleave of the first under the gather of the second (one batch overlaps nothing)
+        Fn = max(1, min(Fn, (K + 1) // 2))
         sf = rr.dist.ShardedFrames(r, W, H, rank, world, torch.device("cuda", local_rank), Fn, always_collective=force_sharded,
                                    rotate_root=args.rotate_root)
         if args.prewarm > 0:
@@ -420,7 +423,7 @@ def main():
                                    "orbit angle 0.01*(k+1), seeded procedural 2048x1024 RGB32F env map",
                        "rays_per_frame": round(total_rays / K, 1),
                        "parallelism": "tiles32x32-roundrobin-x%d%s" % (world, "-rotating-root" if args.rotate_root and world > 1 else ""),
-                       "frames_per_dispatch": min(K, F if world == 1 else F * max(1, min(world // 2, 4))),
+                       "frames_per_dispatch": min(K, F) if world == 1 and not force_sharded else Fn,
                        "prewarm_steps": args.prewarm,
                        "launch_shape": "DispatchRays(W, H, Depth = frames_per_dispatch): every frame complete in its own buffer; the "
                                        "reference's own shape, Depth 1, is roofline.depth1_kernel_us"},
