@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 N_SIMD, CLOCK_GHZ = 1024, 2.4    # 256 CUs x 4 SIMD-32, 2.4 GHz max clock (MI355X_MICROARCH.md)
 # Vector-issue roofline of k_render_fused<19, 2, false, false> (the kernel the headline workload runs on).  The kernel is
 # bound by vector (VALU) issue: the SIMDs hold 8 waves each and every traversal instruction but the f32 add / mul / fma is a
-# quarter-rate one on gfx950 (tools/ubench_valu.hip, profiles/r02_ubench_valu.txt: v_fma_f32 / v_mul_f32 2.2 cycles per
+# quarter-rate one on gfx950 (tools/ubench_valu.hip, profiles/r03_ubench_valu.txt: v_fma_f32 / v_mul_f32 2.2 cycles per
 # wave64 instruction per SIMD, v_cndmask / v_fma_mix_f32 / v_max3 / v_min / v_cmp / v_bfi 4.2, transcendental 8).  A 64-lane
 # wave issues one internal-node step, one triangle test or one shading pass per loop trip however many lanes take part, so
 # its issue time is  node_trips * C_NODE + leaf_trips * C_LEAF + passes * C_PASS + waves * C_WAVE + background_waves * C_BG
@@ -40,7 +40,14 @@ N_SIMD, CLOCK_GHZ = 1024, 2.4    # 256 CUs x 4 SIMD-32, 2.4 GHz max clock (MI355
 # _ADD_F32 / _MUL_F32 / _FMA_F32 / _TRANS_F32 of seven workloads of this kernel (tools/fit_valu.sh, tools/fit_valu.py;
 # residual <= 1.2 %, profiles/r02_valu_fit.txt) and priced with the class costs above.  The trip counters are exact and come
 # from the RR_DISPATCH_COLLECT_STATS launches of the same frames.
-VALU_CYCLES_PER_TRIP = {"node": 130.4,      # 30.5 instructions, all quarter rate (12 of them v_fma_mix_f32)
+# Round 3: tools/ubench_valu.hip now completes (profiles/r03_ubench_valu.txt; round 2's record of it ended in a GPU fault) and
+# its "slab-test mix" row -- the node step's own 29 instructions in the kernel's proportions -- issues at 3.80 cycles per
+# instruction per SIMD with 8 waves resident, less than the 4.2 the single-class rows give: the node trip is priced with that
+# row, 30.5 x 3.80 = 115.9 (round 2: 130.4).  All costs are TRUE shader cycles (wall time x the clock the ubench saw), so the
+# matching peak is SIMDs x the clock the render launch ran at; `peak` uses the 2.4 GHz maximum clock, an upper bound (the
+# launches run at 2.0-2.3 GHz: roofline.clock_seen_GHz, measured live), so `frac` is a lower bound and
+# roofline.frac_at_clock_seen is the same figure over the clock actually held.
+VALU_CYCLES_PER_TRIP = {"node": 115.9,      # 30.5 instructions, all quarter rate (12 of them v_fma_mix_f32), 3.80 cycles each in this mix
                         "leaf": 194.9,      # 61.3: Moller-Trumbore is mostly f32 mul / fma
                         "pass": 856.4,      # 250.0 per shading pass of a traced wave (ray set-up, ClosestHit / Miss)
                         "wave": 299.6,      # 70.7 per traced 8x8 block: RayGen, addressing, store
@@ -68,6 +75,63 @@ def valu_issue_cycles(st):
     bg = st.background_waves
     return (st.node_trips * c["node"] + st.leaf_trips * c["leaf"] + (st.shade_passes - bg) * c["pass"] + (st.waves - bg) * c["wave"]
             + bg * c["bg"])
+
+
+def pmc_busy_roofs(render_kernel, frames_per_launch):
+    """TA / TD / LDS busy fractions of the headline kernel from the latest PMC summary under profiles/ (a counter pass cannot
+    run inside the bench).  They were collected for k_render_fused on monkey.obj 8/2 at Depth 64 and describe nothing else:
+    any other kernel or launch depth gets None."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fused_monkey_d64.txt")))
+    if not cands or render_kernel != 0 or frames_per_launch != 64:
+        return {"l1_texture_addresser_busy": None, "l1_data_return_busy": None, "lds_busy": None,
+                "busy_source": "PMC passes exist for k_render_fused, monkey.obj 8/2, Depth 64 only (%s); this run's shape differs"
+                               % (os.path.relpath(cands[-1], ROOT) if cands else "none under profiles/")}
+    v = {}
+    for line in open(cands[-1]):
+        f = line.split()
+        if len(f) >= 3 and f[1] == "avg_per_launch":
+            v[f[0]] = float(f[2])
+    try:
+        cu_cycles = v["GRBM_GUI_ACTIVE"] / 8.0 * 256.0              # the counter sums 8 XCDs; 256 CUs each with one TA / TD
+        out = {"l1_texture_addresser_busy": round(v["TA_TA_BUSY_sum"] / cu_cycles, 3),
+               "l1_data_return_busy": round(v["TD_TD_BUSY_sum"] / cu_cycles, 3),
+               "lds_busy": round(v["SQ_ACTIVE_INST_LDS"] * 4.0 / (v["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 3)}
+    except KeyError:
+        return {"l1_texture_addresser_busy": None, "l1_data_return_busy": None, "lds_busy": None, "busy_source": "unparsed " + cands[-1]}
+    out["busy_source"] = ("%s: rocprofv3 --pmc passes of k_render_fused<19, 2>, monkey.obj 8/2, Depth 64 (static, the shape of this run). "
+                          "Data-return busy near 1 is not the binding roof: k_render_lds takes the node loads off that path "
+                          "entirely and is no faster on this workload (DESIGN 5.3)" % os.path.relpath(cands[-1], ROOT))
+    return out
+
+
+def issue_record(st, launches, kernel_us, fused_model_applies):
+    """what the vector-issue model says about `launches` launches of `kernel_us` each, from their exact STATS counters"""
+    rec = {"kernel": st.render_kernel_name.decode() if isinstance(st.render_kernel_name, bytes) else str(st.render_kernel_name),
+           "kernel_us": round(kernel_us, 2),
+           "lane_utilisation": {"node": round(st.node_visits / (64.0 * max(st.node_trips, 1)), 3),
+                                "leaf": round(st.tri_tests / (64.0 * max(st.leaf_trips, 1)), 3),
+                                "shade": round(st.rays / (64.0 * max(st.shade_passes, 1)), 3)},
+           "wave_trips_per_launch": {"node": int(st.node_trips / launches), "leaf": int(st.leaf_trips / launches),
+                                     "shade_passes": int(st.shade_passes / launches), "waves": int(st.waves / launches),
+                                     "background_waves": int(st.background_waves / launches)},
+           "clock_seen_GHz": round(st.clock_ghz, 3) if st.clock_ghz else None}
+    if fused_model_applies:
+        cyc = valu_issue_cycles(st) / launches
+        frac = cyc / (kernel_us * 1e-6) / 1e9 / (N_SIMD * CLOCK_GHZ)
+        rec["bound"] = "valu_issue"
+        rec["frac"] = round(frac, 4) if frac <= 1.0 else None
+        if st.clock_ghz:
+            f2 = frac * CLOCK_GHZ / st.clock_ghz
+            rec["frac_at_clock_seen"] = round(f2, 4) if f2 <= 1.0 else None
+        if not frac <= 1.0:
+            rec["model_invalid"] = "fitted vector-issue fraction %.3f > 1: the per-trip costs do not describe this launch" % frac
+    else:
+        rec["bound"] = "not modelled"
+        rec["frac"] = None
+        rec["model_invalid"] = ("the vector-issue model was fitted on k_render_fused<19, 2> (single BLAS); this kernel's trips are "
+                                "reported, its roof is not")
+    return rec
 
 
 def xf(tx, ty, tz, s=1.0):
@@ -122,6 +186,13 @@ def config_records(r, rr, asset, env):
             us = ms / n * 1e3 / frames
             rec["depth%d" % depth] = {"us_per_frame": round(us, 1), "Mrays_per_s": round(st.rays / frames / us, 1),
                                       "rays_per_frame": int(st.rays / frames)}
+            if depth == 16:         # the same launch through the STATS build: trips, lane utilisation, clock, kernel name
+                r.dispatch_rays_batch(W_, H_, cams, rr.default_params(max_refract=refr, flags=rr.DISPATCH_COLLECT_STATS))
+                ss = r.stats()
+                r.dispatch_rays_batch(W_, H_, cams, rr.default_params(max_refract=refr))      # the product build's name
+                name = r.stats().render_kernel_name
+                rec["roofline"] = issue_record(ss, 1, ms / n * 1e3, fused_model_applies=(inst is None and ss.render_kernel == 0))
+                rec["roofline"]["kernel"] = name.decode() if isinstance(name, bytes) else str(name)
         out[key] = rec
     return out
 
@@ -324,7 +395,9 @@ def main():
         kms, kn = r.kernel_time()                                           # HIP events around each launch, on the launch stream
         kernel_us = kms / kn * 1e3
         kn = n_launch                                                       # the counters cover one pass
-        render_kernel = int(r.stats().render_kernel)                        # which kernel those launches were
+        _st = r.stats()
+        render_kernel = int(_st.render_kernel)                              # which kernel those launches were
+        kernel_name = _st.render_kernel_name.decode()
         k1ms, k1n = None, 0
         if not args.no_depth1:   # the reference's own shape, one DispatchRays per frame (RefractionDemo.cpp:589-594: Depth = 1)
             r.render_orbit(W, H, 32, angle=0.01, frames_per_dispatch=1, params=rr.default_params(
@@ -335,9 +408,13 @@ def main():
         achieved = issue_cycles / (kernel_us * 1e-6) / 1e9                  # G SIMD-cycles of vector issue per second
         peak = N_SIMD * CLOCK_GHZ
         frac = achieved / peak
-        if not frac <= 1.0:
-            raise SystemExit("roofline: vector-issue fraction %.3f > 1 -- the per-trip costs no longer describe the kernel; refit "
-                             "(tools/fit_valu.sh) before reporting" % frac)
+        model_invalid = None
+        if render_kernel != 0:
+            model_invalid = "the timed launches ran on render kernel %d, which the k_render_fused issue model does not describe" % render_kernel
+        elif not frac <= 1.0:
+            model_invalid = "fitted vector-issue fraction %.3f > 1: the per-trip costs no longer describe the kernel; refit (tools/fit_valu.sh)" % frac
+        clock_seen = sst.clock_ghz or None
+        frac_seen = frac * CLOCK_GHZ / clock_seen if clock_seen else None
         bytes_per_launch = algorithmic_bytes(sst) / kn
         traffic = None
         import glob
@@ -350,13 +427,18 @@ def main():
                                      % os.path.relpath(cands[-1], ROOT)}
             except Exception:
                 traffic = None
-        kernel_names = {0: ROOFLINE_KERNEL, 1: "k_render_lds<12, 2, false, false> (RR_DEBUG_KERNEL=lds; the issue model was fitted on k_render_fused)",
-                        2: "k_render_paths"}
+        busy = pmc_busy_roofs(render_kernel, Fl)
         roofline = {"bound": "valu_issue", "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "G SIMD-cycles/s",
-                    "frac": round(frac, 4), "traffic": traffic,
-                    "kernel": kernel_names.get(render_kernel, "?"), "kernel_us": round(kernel_us, 2), "frames_per_launch": Fl,
+                    "frac": None if model_invalid else round(frac, 4), "traffic": traffic,
+                    "peak_note": "%d SIMDs x %.1f GHz, the maximum clock: an upper bound, so frac is a lower bound; the launches ran at "
+                                 "clock_seen_GHz (s_memtime / s_memrealtime over every wave of the STATS launches of the same frames)" % (N_SIMD, CLOCK_GHZ),
+                    "clock_seen_GHz": round(clock_seen, 3) if clock_seen else None,
+                    "frac_at_clock_seen": None if (model_invalid or not frac_seen or frac_seen > 1.0) else round(frac_seen, 4),
+                    "model_invalid": model_invalid,
+                    "kernel": kernel_name, "kernel_us": round(kernel_us, 2), "frames_per_launch": Fl,
                     "model": "node_trips*%.1f + leaf_trips*%.1f + (shade_passes - background_waves)*%.1f + (waves - background_waves)*%.1f + "
-                             "background_waves*%.1f SIMD cycles (profiles/r02_valu_fit.txt, profiles/r02_ubench_valu.txt); %d SIMDs x %.1f GHz" % (
+                             "background_waves*%.1f SIMD cycles (instruction counts: profiles/r02_valu_fit.txt; cycles per class and the node mix: "
+                             "profiles/r03_ubench_valu.txt); %d SIMDs x %.1f GHz" % (
                                  VALU_CYCLES_PER_TRIP["node"], VALU_CYCLES_PER_TRIP["leaf"], VALU_CYCLES_PER_TRIP["pass"],
                                  VALU_CYCLES_PER_TRIP["wave"], VALU_CYCLES_PER_TRIP["bg"], N_SIMD, CLOCK_GHZ),
                     "wave_trips_per_launch": {"node": int(sst.node_trips / kn), "leaf": int(sst.leaf_trips / kn),
@@ -367,12 +449,13 @@ def main():
                                          "shade": round(sst.rays / (64.0 * sst.shade_passes), 3)},
                     # the other candidate roofs, as fractions of their peaks (rocprofv3 PMC passes of this kernel at this shape,
                     # profiles/r02_pmc_fused_monkey_d64.txt; static -- a counter pass cannot run inside the bench):
-                    "roofs": {"valu_issue": round(frac, 4), "l1_texture_addresser_busy": 0.84, "l1_data_return_busy": 0.98,
+                    "roofs": {"valu_issue": None if model_invalid else round(frac, 4),
+                              "l1_texture_addresser_busy": busy["l1_texture_addresser_busy"], "l1_data_return_busy": busy["l1_data_return_busy"],
                               "hbm_counter_bytes": (round(traffic["hbm_bytes_per_launch"] / traffic["frames_per_launch"] * Fl / (kernel_us * 1e-6) / (HBM_PEAK_GBS * 1e9), 4)
                                                     if traffic and traffic.get("hbm_bytes_per_launch") else None),
-                              "lds_busy": 0.03,
+                              "lds_busy": busy["lds_busy"],
                               "source": "valu_issue live (exact trip counters x fitted per-trip cost); hbm_counter_bytes = the PMC bytes of "
-                                        "roofline.traffic over this run's kernel time and 8 TB/s; TA / TD / LDS busy from profiles/r02_pmc_fused_monkey_d64.txt"},
+                                        "roofline.traffic over this run's kernel time and 8 TB/s; TA / TD / LDS busy: " + busy["busy_source"]},
                     "depth1_kernel_us": round(k1ms / k1n * 1e3, 2) if k1n else None,
                     "algorithmic_bytes_per_launch": int(bytes_per_launch),
                     "algorithmic_GBps_not_a_roof": round(bytes_per_launch / (kernel_us * 1e-6) / 1e9, 1),
@@ -398,6 +481,24 @@ def main():
                 raise SystemExit("traversal stack overflow on the subdivided mesh: result invalid")
             subdiv = {"workload": "monkey.obj midpoint-subdivided x2 (%d tri), otherwise as config.workload" % (len(i16) // 3),
                       "value": round(s16.rays / t16 / 1e6, 2), "unit": "Mrays/s", "fps": round(n16 / t16, 1), "steps": n16}
+            # its roof: one launch of F frames through the STATS build (exact trips, clock) and three through the product build
+            # with HIP events.  The per-trip costs were fitted on k_render_fused<19, 2> (32-bit stack entries); this mesh's tree
+            # is deeper and runs the 16-bit-stack instantiation of the same loops (two more vector instructions per push / pop),
+            # so the fraction is the model's estimate for it, labelled as such.
+            r.render_orbit(W, H, F, angle=0.01, frames_per_dispatch=F, params=rr.default_params(
+                max_refract=MAX_REFRACT, max_reflect=MAX_REFLECT, flags=rr.DISPATCH_COLLECT_STATS))
+            ss16 = r.stats()
+            for _ in range(3):
+                r.render_orbit(W, H, F, angle=0.01, frames_per_dispatch=F, params=rr.default_params(
+                    max_refract=MAX_REFRACT, max_reflect=MAX_REFLECT, flags=rr.DISPATCH_TIME_KERNEL))
+            ms16, n16k = r.kernel_time()
+            name16 = r.stats().render_kernel_name.decode()
+            subdiv["roofline"] = issue_record(ss16, 1, ms16 / n16k * 1e3, fused_model_applies=ss16.render_kernel == 0)
+            subdiv["roofline"]["kernel"] = name16
+            subdiv["roofline"]["frames_per_launch"] = F
+            subdiv["roofline"]["model_note"] = "per-trip costs fitted on k_render_fused<19, 2, ..., unsigned int>; applied to this instantiation as an estimate"
+            subdiv["roofline"]["node_visits_per_ray"] = round(ss16.node_visits / ss16.rays, 2)
+            subdiv["roofline"]["tri_tests_per_ray"] = round(ss16.tri_tests / ss16.rays, 2)
             r.load_scene(mesh.verts, mesh.indices, env)
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(mesh, env)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RRDXR_ABI_VERSION 2
+#define RRDXR_ABI_VERSION 3
 
 typedef enum rr_status {
     RR_OK = 0,
@@ -85,6 +85,10 @@ typedef struct rr_dispatch_params {
 #define RR_DISPATCH_TONEMAP_REINHARD 0x20u /* SURVEY 8f.2, additive: the R8G8B8A8_UNORM store takes c / (1 + c) per channel (NaN and
                                               negative -> 0, +inf -> 1) instead of the reference's saturating c; the float frame
                                               (RR_DISPATCH_FLOAT_OUTPUT) stays linear.  Off by default = RayTracing.hlsl:62 */
+#define RR_DISPATCH_DEBUG_NO_CULL 0x40u /* verification switch: treat the whole frame as the scene's screen rectangle, i.e. trace the
+                                           primary ray of EVERY pixel (RayTracing.hlsl:60) instead of shading the blocks the host
+                                           projection of the scene bounds rules out as one Miss.  Frames are identical by
+                                           contract (tests/test_gpu_parity.py::test_background_culling_...); only slower */
 
 typedef struct rr_stats {
     uint64_t rays;                /* every TraceRay: primary + secondary */
@@ -112,6 +116,12 @@ typedef struct rr_stats {
     uint64_t waves;               /* waves that rendered (one 8x8 pixel block each in the block-per-wave kernels) */
     uint64_t background_waves;    /* of those, the waves of blocks outside the scene's screen rectangle: RayGen + one Miss
                                      (counted in shade_passes too), on a branch of their own in k_render_fused */
+    /* ABI 3: the clock the RR_DISPATCH_COLLECT_STATS launches ran at = clock_ticks / clock_ref_ticks * 100 MHz (sums over the
+     * waves of their lifetime on the shader clock, s_memtime, and on the constant 100 MHz reference, s_memrealtime) */
+    uint64_t clock_ticks;
+    uint64_t clock_ref_ticks;
+    char     render_kernel_name[96]; /* the instantiation that rendered the last dispatch, as rocprofv3 --kernel-trace names it
+                                        (less the argument list), e.g. "k_render_fused<19, 2, false, false, false, unsigned int, 0>" */
 } rr_stats;
 
 typedef struct rr_ray {

@@ -17,6 +17,7 @@ DISPATCH_TIME_KERNEL = 0x4
 DISPATCH_KEEP_COUNTERS = 0x8
 DISPATCH_TILES_RGB8 = 0x10
 DISPATCH_TONEMAP_REINHARD = 0x20
+DISPATCH_DEBUG_NO_CULL = 0x40
 BUILD_PREFER_FAST_TRACE = 0x4
 BUILD_PREFER_FAST_BUILD = 0x8
 RAY_FLAG_CULL_BACK = 0x10
@@ -58,7 +59,13 @@ class Stats(C.Structure):
                 ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("pixels", C.c_uint64),
                 ("stats_valid", C.c_uint32), ("traversal_overflow", C.c_uint32), ("bvh_depth", C.c_uint32),
                 ("render_kernel", C.c_uint32), ("node_trips", C.c_uint64), ("leaf_trips", C.c_uint64),
-                ("shade_passes", C.c_uint64), ("waves", C.c_uint64), ("background_waves", C.c_uint64)]
+                ("shade_passes", C.c_uint64), ("waves", C.c_uint64), ("background_waves", C.c_uint64),
+                ("clock_ticks", C.c_uint64), ("clock_ref_ticks", C.c_uint64), ("render_kernel_name", C.c_char * 96)]
+
+    @property
+    def clock_ghz(self):
+        """shader clock of the COLLECT_STATS launches (s_memtime / s_memrealtime x 100 MHz), 0.0 without them"""
+        return self.clock_ticks / self.clock_ref_ticks * 0.1 if self.clock_ref_ticks else 0.0
 
 
 # every symbol include/rrdxr.h declares: name -> (restype, argtypes)
@@ -150,7 +157,7 @@ def lib():
             fn = getattr(L, name)      # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.rr_abi_version() != 2:
+        if L.rr_abi_version() != 3:
             raise RuntimeError("librrdxr.so ABI version mismatch")
         _lib = L
     return _lib

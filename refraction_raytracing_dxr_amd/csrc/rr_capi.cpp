@@ -155,6 +155,7 @@ struct rr_context {
     // kernel by 6 % all round the orbit; monkey.obj: the L1-fed one by 2 %), and which does depends on how busy the texture
     // path is, not on anything the host can see.  So the first two eligible launches of a scene are timed with HIP events, one
     // on each kernel (adjacent slices of the same orbit), and the faster per slice renders the rest.  Frames are bit-identical.
+    char       last_kernel_name[96] = "";
     uint32_t   last_kernel = 0;      // render kernel of the last dispatch: 0 k_render_fused, 1 k_render_lds, 2 k_render_paths, 3 experimental
     uint32_t* d_tickets = nullptr;   // k_render_lds ticket words: one block per stream a launch can be on (lanes, then the context's stream)
 
@@ -741,32 +742,50 @@ int ensure_lane(rr_context* ctx, uint32_t lane)
 // Screen rectangle (pixels, aligned outward to 8x8 blocks, 8 pixels of margin) that contains the projection of the box
 // {lo[3], hi[3]} for every one of the n slices' constants.  GenerateCameraRay (RayTracing.hlsl:27-40) sends pixel s to
 // the direction A * (sx, sy, 1) with A = columns 0, 1, 3 of proj_inv's upper three rows, so a point X is seen at
-// (a/c, b/c) where A * (a, b, c) = X - camera_loc, provided c > 0.  A corner at or behind the camera plane makes the
-// rectangle the whole frame.  Only an ordering hint for k_render_lds: pixels outside it are rendered all the same.
+// (a/c, b/c) where A * (a, b, c) = X - camera_loc, provided c > 0.
+// This rectangle is a CORRECTNESS path, not a hint: k_render_fused and k_render_paths do not trace the primary rays of
+// blocks outside it (their pixels are one Miss), and k_render_lds orders its work by it.  So it has to hold for the rays
+// the kernels really generate, which are fp32: R = (sx*M0 + sy*M1) + M3 per row carries an absolute error of a few
+// 2^-24 * (|M0| + |M1| + |M3|), i.e. the fp32 ray of pixel s is the exact ray of a pixel up to ||A^-1|| * that error away.
+// The 8-pixel margin (16 / max(W, H) in screen units, of which a quarter is spent here) therefore only covers matrices
+// whose condition number cond_inf(A) = ||A||_inf * ||A^-1||_inf stays below margin / 2^-20; anything worse -- a singular or
+// near-singular proj_inv, non-finite constants, a corner at or behind the camera plane (the camera inside or beside the
+// box), a projection that overflows -- makes the rectangle the whole frame, which is always right.
+// cams == nullptr (RR_DISPATCH_DEBUG_NO_CULL, and callers without a host copy of the constants): the whole frame.
 void mesh_screen_rect(const float box[6], const rr_scene_constants* cams, uint32_t n, uint32_t W, uint32_t H, uint32_t r[4])
 {
     double x0 = 1e30, y0 = 1e30, x1 = -1e30, y1 = -1e30;
     bool all = cams == nullptr;
+    for (int k = 0; k < 6 && !all; ++k) if (!std::isfinite(box[k])) all = true;
+    const double margin_s = 16.0 / (double)std::max(W, H);          // 8 pixels in screen units (the frame spans 2)
     for (uint32_t f = 0; f < n && !all; ++f) {
         const float* M = cams[f].proj_inv;
         const double A[3][3] = { { M[0], M[1], M[3] }, { M[4], M[5], M[7] }, { M[8], M[9], M[11] } };
-        const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
-                           A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
-        if (!(std::fabs(det) > 1e-30)) { all = true; break; }
+        double norm_a = 0.0;
+        for (int i = 0; i < 3; ++i) norm_a = std::max(norm_a, std::fabs(A[i][0]) + std::fabs(A[i][1]) + std::fabs(A[i][2]));
+        for (int i = 0; i < 3; ++i) if (!std::isfinite(cams[f].camera_loc[i])) all = true;
+        if (all || !std::isfinite(norm_a) || !(norm_a > 0.0)) { all = true; break; }
+        // adjugate (cofactors transposed): A^-1 = adj / det
+        const double adj[3][3] = {
+            { A[1][1] * A[2][2] - A[1][2] * A[2][1], A[0][2] * A[2][1] - A[0][1] * A[2][2], A[0][1] * A[1][2] - A[0][2] * A[1][1] },
+            { A[1][2] * A[2][0] - A[1][0] * A[2][2], A[0][0] * A[2][2] - A[0][2] * A[2][0], A[0][2] * A[1][0] - A[0][0] * A[1][2] },
+            { A[1][0] * A[2][1] - A[1][1] * A[2][0], A[0][1] * A[2][0] - A[0][0] * A[2][1], A[0][0] * A[1][1] - A[0][1] * A[1][0] } };
+        const double det = A[0][0] * adj[0][0] + A[0][1] * adj[1][0] + A[0][2] * adj[2][0];
+        double norm_adj = 0.0;
+        for (int i = 0; i < 3; ++i) norm_adj = std::max(norm_adj, std::fabs(adj[i][0]) + std::fabs(adj[i][1]) + std::fabs(adj[i][2]));
+        // cond = norm_a * norm_adj / |det|; require cond * 2^-20 <= margin_s / 4 (written without the division)
+        if (!std::isfinite(det) || !std::isfinite(norm_adj) || !(std::fabs(det) * margin_s * 0.25 >= norm_a * norm_adj * 9.5367431640625e-07)) { all = true; break; }
         for (int c = 0; c < 8 && !all; ++c) {
             const double d[3] = { (double)((c & 1) ? box[3] : box[0]) - cams[f].camera_loc[0],
                                   (double)((c & 2) ? box[4] : box[1]) - cams[f].camera_loc[1],
                                   (double)((c & 4) ? box[5] : box[2]) - cams[f].camera_loc[2] };
-            // Cramer's rule
-            const double da = d[0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (d[1] * A[2][2] - A[1][2] * d[2]) +
-                              A[0][2] * (d[1] * A[2][1] - A[1][1] * d[2]);
-            const double db = A[0][0] * (d[1] * A[2][2] - A[1][2] * d[2]) - d[0] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
-                              A[0][2] * (A[1][0] * d[2] - d[1] * A[2][0]);
-            const double dc = A[0][0] * (A[1][1] * d[2] - d[1] * A[2][1]) - A[0][1] * (A[1][0] * d[2] - d[1] * A[2][0]) +
-                              d[0] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
-            const double cc = dc / det;
-            if (!(cc > 1e-6)) { all = true; break; }
-            const double sx = da / det / cc, sy = db / det / cc;
+            const double a = (adj[0][0] * d[0] + adj[0][1] * d[1] + adj[0][2] * d[2]) / det;
+            const double b = (adj[1][0] * d[0] + adj[1][1] * d[1] + adj[1][2] * d[2]) / det;
+            const double cc = (adj[2][0] * d[0] + adj[2][1] * d[1] + adj[2][2] * d[2]) / det;
+            // in front of the camera plane by a margin relative to the corner's own size in these coordinates (a corner
+            // near the plane projects to infinity, and its sign is not to be trusted)
+            if (!(cc > 1e-4 * (std::fabs(a) + std::fabs(b) + std::fabs(cc))) || !(cc > 0.0)) { all = true; break; }
+            const double sx = a / cc, sy = b / cc;
             const double px = (sx + 1.0) * 0.5 * W - 0.5, py = (1.0 - sy) * 0.5 * H - 0.5;
             if (!(std::fabs(px) < 1e9 && std::fabs(py) < 1e9)) { all = true; break; }
             x0 = std::min(x0, px); x1 = std::max(x1, px); y0 = std::min(y0, py); y1 = std::max(y1, py);
@@ -826,7 +845,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     a.async_leaf_num = ctx->dbg_async[0]; a.async_shade_num = ctx->dbg_async[1];
     {   // where the scene can be seen at all in these slices
         uint32_t hr[4];
-        mesh_screen_rect(ctx->scene_bounds, h_cams, depth, width, height, hr);
+        mesh_screen_rect(ctx->scene_bounds, (p.flags & RR_DISPATCH_DEBUG_NO_CULL) ? nullptr : h_cams, depth, width, height, hr);
         a.hx0 = hr[0]; a.hy0 = hr[1]; a.hx1 = hr[2]; a.hy1 = hr[3];
     }
     if (ctx->dbg_tile_order && ctx->tile_world == 1 && n_tiles < 65536u && a.hx1 > a.hx0 && a.hy1 > a.hy0) {
@@ -1014,6 +1033,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         (void)hipFree(d_diag);
         if (FILE* f = fopen(diag_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
+    snprintf(ctx->last_kernel_name, sizeof ctx->last_kernel_name, "%s", (wavefront || refill_kernel || scene_async || scene_stream) ? "(experiment)" : last_render_kernel_name());
     ctx->last_kernel = wavefront ? 3u : paths_kernel ? 2u : refill_kernel ? 4u : scene_async ? 5u : scene_stream ? 6u : lds_kernel ? 1u : 0u;
     ctx->W = width; ctx->H = height; ctx->frame_world = ctx->tile_world; ctx->frame_depth = depth;
     ctx->have_f32 = want_f32; ctx->have_frame = ext_tiles == nullptr; ctx->have_assembled = false;
@@ -1496,7 +1516,9 @@ int rr_get_stats(rr_context* ctx, rr_stats* out)
         out->tir = h->counters[C_TIR]; out->node_visits = h->counters[C_NODES]; out->tri_tests = h->counters[C_TRIS];
         out->node_trips = h->counters[C_NODE_TRIPS]; out->leaf_trips = h->counters[C_LEAF_TRIPS];
         out->shade_passes = h->counters[C_PASSES]; out->waves = h->counters[C_WAVES]; out->background_waves = h->counters[C_BG_WAVES];
+        out->clock_ticks = h->counters[C_CLK_TICKS]; out->clock_ref_ticks = h->counters[C_CLK_REAL];
     }
+    memcpy(out->render_kernel_name, ctx->last_kernel_name, sizeof out->render_kernel_name);
     out->traversal_overflow = h->error;
     out->bvh_depth = scene_stack_need(ctx);
     out->render_kernel = ctx->last_kernel;

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256, WPS ? WPS : TLAS ? RR_TLAS_WAVES_PER_SIMD(STAC
     float4* const out_f32 = a.out_f32 ? a.out_f32 + (size_t)bp.frame * a.frame_stride : nullptr;
 
     LaneStats st;
+    stats_clock_begin<STATS>(st);
     st.blocks = bp.tile_ok ? 1u : 0u;
     if (STATS && bp.tile_ok && !(DIAG || (bp.x0 + 8u > a.hx0 && bp.x0 < a.hx1 && bp.y0 + 8u > a.hy0 && bp.y0 < a.hy1))) st.bg_blocks = 1u;
     if (valid) {
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(256, TLAS ? 5 : 8) void k_render_paths(SceneDev sc,
     const unsigned long long diag_t0 = DIAG ? __builtin_amdgcn_s_memrealtime() : 0ull;
     if (DIAG) { if (lane < 16u) diag_lv[wave][lane] = 0u; }
     LaneStats st;
+    stats_clock_begin<STATS>(st);
     if (blockIdx.x < n_pp_blocks) {
         uint32_t* stk = lds + wave * (STACK * 64) + lane;
         const uint32_t frame = blockIdx.x % a.n_frames, b = blockIdx.x / a.n_frames;
@@ -261,6 +263,7 @@ __global__ __launch_bounds__(NW * 64, NW * WGS / 4) void k_render_lds(SceneDev s
     const uint32_t lx = compact1by1(lane), ly = compact1by1(lane >> 1);
 
     LaneStats st;
+    stats_clock_begin<STATS>(st);
     auto in_rect = [&](const BlockPos& bp) { return bp.x0 >= q.rx0 && bp.x0 < q.rx1 && bp.y0 >= q.ry0 && bp.y0 < q.ry1; };
     // The wave's work loop.  Everything that decides WHICH block comes next is wave-uniform (scalar); the renderer itself is
     // instantiated once, at the bottom of the loop (its code is ~10 KB: several inlined copies thrash the instruction cache).
@@ -488,10 +491,15 @@ __global__ __launch_bounds__(256) void k_assemble_frames_rgb8(const uint8_t* __r
 
 
 // ------------------------------------------------------------------------------------ launchers
+// name of the render kernel instantiation the calling thread launched last (rr_stats::render_kernel_name)
+static thread_local char g_kernel_name[96] = "";
+const char* last_render_kernel_name() { return g_kernel_name; }
+#define RR_NAME(...) snprintf(g_kernel_name, sizeof g_kernel_name, __VA_ARGS__)
 template <int STACK, int PEND, bool TLAS>
 static hipError_t launch_fused_spt(const SceneDev& sc, const DispatchDev& a, bool stats, hipStream_t s)
 {
     const size_t lds = (size_t)4 * STACK * 64 * sizeof(uint32_t);
+    RR_NAME("k_render_fused<%d, %d, %s, %s, false, unsigned int, 0>", STACK, PEND, stats ? "true" : "false", TLAS ? "true" : "false");
     if (stats) hipLaunchKernelGGL((k_render_fused<STACK, PEND, true, TLAS>), dim3(a.n_blocks), dim3(256), lds, s, sc, a);
     else       hipLaunchKernelGGL((k_render_fused<STACK, PEND, false, TLAS>), dim3(a.n_blocks), dim3(256), lds, s, sc, a);
     return hipGetLastError();
@@ -507,6 +515,7 @@ static hipError_t launch_lds_nw(const SceneDev& sc, const DispatchDev& a, const 
     }();
     if (attr != hipSuccess) return attr;
     const dim3 grid((uint32_t)n_cus * WGS), block(NW * 64);
+    RR_NAME("k_render_lds<%d, %d, %s, false>", NW, WGS, stats ? "true" : "false");
     if (stats) hipLaunchKernelGGL((k_render_lds<NW, WGS, true>), grid, block, lds, s, sc, a, q);
     else       hipLaunchKernelGGL((k_render_lds<NW, WGS, false>), grid, block, lds, s, sc, a, q);
     return hipGetLastError();
@@ -572,6 +581,7 @@ template <int PEND>
 static hipError_t launch_fused_s16(const SceneDev& sc, const DispatchDev& a, bool stats, hipStream_t s)
 {
     const size_t lds = (size_t)4 * 39 * 64 * sizeof(uint16_t);
+    RR_NAME("k_render_fused<39, %d, %s, false, false, unsigned short, 0>", PEND, stats ? "true" : "false");
     if (stats) hipLaunchKernelGGL((k_render_fused<39, PEND, true, false, false, uint16_t>), dim3(a.n_blocks), dim3(256), lds, s, sc, a);
     else       hipLaunchKernelGGL((k_render_fused<39, PEND, false, false, false, uint16_t>), dim3(a.n_blocks), dim3(256), lds, s, sc, a);
     return hipGetLastError();
@@ -589,6 +599,7 @@ template <int STACK, int WPS>
 static hipError_t launch_fused_tlas16(const SceneDev& sc, const DispatchDev& a, bool stats, hipStream_t s)
 {
     const size_t lds = (size_t)4 * STACK * 64 * sizeof(uint16_t);
+    RR_NAME("k_render_fused<%d, 2, %s, true, false, unsigned short, %d>", STACK, stats ? "true" : "false", WPS);
     if (stats) hipLaunchKernelGGL((k_render_fused<STACK, 2, true, true, false, uint16_t, WPS>), dim3(a.n_blocks), dim3(256), lds, s, sc, a);
     else       hipLaunchKernelGGL((k_render_fused<STACK, 2, false, true, false, uint16_t, WPS>), dim3(a.n_blocks), dim3(256), lds, s, sc, a);
     return hipGetLastError();
@@ -634,6 +645,7 @@ static hipError_t launch_paths_st(const SceneDev& sc, const DispatchDev& a, uint
 {
     const size_t lds = (size_t)4 * STACK * 64 * sizeof(uint32_t);
     const dim3 grid(n_pp + a.n_blocks);
+    RR_NAME("k_render_paths<%d, %s, %s, false>", STACK, stats ? "true" : "false", TLAS ? "true" : "false");
     if (a.diag && !TLAS) { hipLaunchKernelGGL((k_render_paths<STACK, false, false, true>), grid, dim3(256), lds, s, sc, a, n_pp, rect_bw); return hipGetLastError(); }
     if (stats) hipLaunchKernelGGL((k_render_paths<STACK, true, TLAS>), grid, dim3(256), lds, s, sc, a, n_pp, rect_bw);
     else       hipLaunchKernelGGL((k_render_paths<STACK, false, TLAS>), grid, dim3(256), lds, s, sc, a, n_pp, rect_bw);

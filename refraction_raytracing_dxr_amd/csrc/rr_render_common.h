@@ -55,8 +55,13 @@ struct LaneStats {
     uint32_t passes = 0;            // wave-level shading passes (ray rounds), STATS builds
     uint32_t blocks = 0;            // 8x8 pixel blocks this wave rendered (wave-uniform)
     uint32_t bg_blocks = 0;         // of those, background blocks rendered on the RayGen + Miss branch (wave-uniform)
+    unsigned long long clk0 = 0, rt0 = 0;   // STATS builds: the wave's start on the shader clock and on the 100 MHz reference
     TravCounters cnt = { 0, 0 };
 };
+template <bool STATS> __device__ __forceinline__ void stats_clock_begin(LaneStats& st)
+{
+    if (STATS) { st.clk0 = __builtin_amdgcn_s_memtime(); st.rt0 = __builtin_amdgcn_s_memrealtime(); }
+}
 
 // One pixel: RayGen (RayTracing.hlsl:42-64), then the pixel's whole ray tree depth-first -- ClosestHit (hlsl:79-125)
 // spawns the refracted child (followed at once) and the reflected child (parked in registers), Miss (hlsl:127-137)
@@ -244,6 +249,10 @@ __device__ __forceinline__ void flush_stats(const DispatchDev& a, const LaneStat
         v = wave_reduce_add(st.passes); if (lane == 0 && v) atomicAdd(&a.counters[C_PASSES], (unsigned long long)v);
         if (lane == 0 && st.blocks) atomicAdd(&a.counters[C_WAVES], (unsigned long long)st.blocks);
         if (lane == 0 && st.bg_blocks) atomicAdd(&a.counters[C_BG_WAVES], (unsigned long long)st.bg_blocks);
+        if (lane == 0 && st.blocks) {
+            atomicAdd(&a.counters[C_CLK_TICKS], (unsigned long long)(__builtin_amdgcn_s_memtime() - st.clk0));
+            atomicAdd(&a.counters[C_CLK_REAL], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - st.rt0));
+        }
     }
 }
 

@@ -173,6 +173,8 @@ enum Counter : int {
     C_RAYS = 0, C_PRIMARY, C_SECONDARY, C_HITS, C_MISSES, C_TERMINAL, C_TIR, C_NODES, C_TRIS,
     C_NODE_TRIPS, C_LEAF_TRIPS, C_PASSES, C_WAVES,      // wave-level loop trips of the STATS builds (what the vector unit issues for)
     C_BG_WAVES,                                         // waves of background blocks (k_render_fused's RayGen + Miss branch)
+    C_CLK_TICKS, C_CLK_REAL,                            // STATS builds: sum over waves of their lifetime in shader-clock ticks (s_memtime) and on the
+                                                        // 100 MHz reference (s_memrealtime): the clock the launch ran at = ticks / real * 100 MHz
     C_COUNT
 };
 constexpr int RAY_SHARDS = 1024;

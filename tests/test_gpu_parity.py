@@ -684,6 +684,124 @@ def test_instanced_scene_parity(gpu):
     check_frame(*render_both(gpu, s, 0.6, 200, 150, max_refract=8))
 
 
+# ------------------------------------------------------------------------------- background culling
+def adversarial_constants(rng, kind, box_lo, box_hi):
+    """SceneConstants as rr_set_camera accepts them (any proj_inv, any camera_loc): the orbit camera's constants pushed
+    towards everything the host-side screen rectangle of the scene has to survive."""
+    fov = np.deg2rad(rng.choice([1.0, 5.0, 30.0, 60.0, 95.0, 140.0, 170.0])) if kind == "fov" else rr.FOV_Y
+    aspect = float(rng.choice([0.2, 1.0, 16.0 / 9.0, 5.0])) if kind in ("fov", "skew") else rr.ASPECT
+    sc = rr.camera_orbit(float(rng.uniform(0.0, 6.28)), fov_y=float(fov), aspect=aspect)
+    M = np.array(sc.proj_inv, np.float32).reshape(4, 4).copy()
+    cam = np.array(sc.camera_loc, np.float32).copy()
+    ctr, half = 0.5 * (box_lo + box_hi), 0.5 * (box_hi - box_lo)
+    if kind == "radius":                    # from deep inside the bounds to far away, through the faces
+        cam[:3] = cam[:3] * np.float32(rng.choice([0.0, 0.3, 0.7, 1.0, 1.5, 2.5, 4.0, 20.0]))
+    elif kind == "on_bounds":               # on a corner / a face of the bounds, and a hair outside them
+        sgn = rng.choice([-1.0, 1.0], 3)
+        p = ctr + sgn * half * np.where(rng.random(3) < 0.5, 1.0, rng.uniform(0.0, 1.0, 3))
+        cam[:3] = (p + sgn * rng.choice([0.0, 1e-6, 1e-3, 0.05])).astype(np.float32)
+    elif kind in ("skew", "singular", "mirror", "random"):
+        A = M[:3][:, [0, 1, 3]].astype(np.float64)
+        if kind == "random":
+            A = rng.normal(size=(3, 3))
+        elif kind == "singular":            # singular values spread over 2..9 decades, in a random frame
+            U, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+            V, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+            spread = 10.0 ** rng.uniform(2.0, 9.0)
+            A = A @ (U @ np.diag([1.0, spread ** -0.5, 1.0 / spread]) @ V.T)
+        else:                               # shear + anisotropic scale of the screen axes (the scene stays in view), optionally mirrored
+            S = np.eye(3) + rng.uniform(-0.35, 0.35, (3, 3)) * np.array([[1, 1, 0.3], [1, 1, 0.3], [0.2, 0.2, 0.2]])
+            S = S @ np.diag([10.0 ** rng.uniform(-0.7, 0.7), 10.0 ** rng.uniform(-0.7, 0.7), 1.0])
+            if kind == "mirror":
+                S = S @ np.diag([[1.0, -1.0, 1.0], [-1.0, 1.0, 1.0], [-1.0, -1.0, 1.0]][int(rng.integers(3))])
+            A = A @ S
+        M[:3][:, [0, 1, 3]] = A.astype(np.float32)
+        if rng.random() < 0.3:
+            cam[:3] = cam[:3] * np.float32(rng.choice([0.5, 2.0, 8.0]))
+    return rr.scene_constants(M, cam), M, cam
+
+
+CULL_KINDS = ["fov", "radius", "on_bounds", "skew", "singular", "mirror", "random"]
+CULL_SIZES = [(640, 360), (8, 8), (257, 131), (2049, 3), (800, 200), (64, 40), (333, 500), (3, 1025), (1200, 96)]
+
+
+@pytest.mark.parametrize("scene", ["monkey", "sphere_small", "tlas"])
+def test_background_culling_equals_tracing_every_primary_ray(gpu, scene):
+    """k_render_fused / k_render_paths shade the 8x8 blocks outside the host-side screen rectangle of the scene bounds as one
+    Miss, without TraceRay (RayTracing.hlsl:60 traces every pixel).  For a few hundred constants rr_set_camera accepts --
+    fov 1..170 degrees, cameras inside / on / just outside the bounds, skewed, mirrored, near-singular and random proj_inv --
+    the frame must equal the same dispatch with RR_DISPATCH_DEBUG_NO_CULL (every primary ray traced), Depth 1
+    (k_render_paths where the rectangle is small) and Depth 3 (k_render_fused); a subset is checked against the oracle."""
+    env = procedural_env(128, 64, seed=21)
+    inst = None
+    if scene == "monkey":
+        meshes = [load("monkey.obj")]
+    elif scene == "sphere_small":
+        m = load("sphere.obj")
+        v = m.verts.copy(); v["position"] = v["position"] * np.float32(0.15) + np.array([0.4, -0.2, 0.1], np.float32)
+        m.verts = v
+        meshes = [m]
+    else:
+        def xf(tx, ty, tz, s):
+            return np.concatenate([np.eye(3, dtype=np.float32) * np.float32(s), np.array([[tx], [ty], [tz]], np.float32)], axis=1)
+        meshes = [load("cube.obj"), load("monkey.obj")]
+        inst = rr.make_instances(transforms=[xf(0, 0, 0, 0.6), xf(1.2, 0.3, -0.8, 0.3), xf(-0.9, -0.4, 0.7, 0.4)], meshes=[1, 0, 1])
+    gpu_scene(gpu, meshes, env, inst)
+    s = oracle_scene(meshes, env, inst)
+    lo = np.min([m.verts["position"].min(axis=0) for m in meshes], axis=0).astype(np.float64)
+    hi = np.max([m.verts["position"].max(axis=0) for m in meshes], axis=0).astype(np.float64)
+    if inst is not None:
+        lo, hi = np.array([-1.5, -1.0, -1.2]), np.array([1.6, 1.0, 1.2])
+    rng = np.random.default_rng({"monkey": 1, "sphere_small": 2, "tlas": 3}[scene])
+    gpu.set_tile_partition(0, 1)
+    culled_cases = oracle_cases = 0
+    culled_by_kind = dict.fromkeys(CULL_KINDS, 0)
+    n_cases = 126
+    for k in range(n_cases):
+        kind = CULL_KINDS[k % len(CULL_KINDS)]
+        W, H = CULL_SIZES[(k // len(CULL_KINDS)) % len(CULL_SIZES)]
+        depth = 1 if (k // 3) % 2 == 0 else 3
+        cams = [adversarial_constants(rng, kind, lo, hi) for _ in range(depth)]
+        kw = dict(max_refract=int(rng.choice([0, 2, 6])), max_reflect=int(rng.choice([0, 2])))
+        out = []
+        for extra in (0, rr.DISPATCH_DEBUG_NO_CULL):
+            p = rr.default_params(flags=rr.DISPATCH_FLOAT_OUTPUT | rr.DISPATCH_COLLECT_STATS | extra, **kw)
+            if depth == 1:
+                gpu.set_camera(cams[0][0]); gpu.dispatch_rays(W, H, p)
+            else:
+                gpu.dispatch_rays_batch(W, H, [c[0] for c in cams], p)
+            frames = [gpu.read_frame(want_float=True, slice=f) for f in range(depth)]
+            out.append((frames, gpu.stats()))
+        (fc, stc), (fn, stn) = out
+        # (8x8 blocks of the 32x32 tiles that lie beyond the frame's edge count as background blocks in both runs)
+        beyond = (((W + 31) // 32) * ((H + 31) // 32) * 16 - ((W + 7) // 8) * ((H + 7) // 8)) * depth
+        assert stn.background_waves == beyond
+        # the culled branch ran: k_render_fused counted background blocks inside the frame, or the launch went to k_render_paths
+        # (render_kernel 2), which is only chosen where the rectangle is under a quarter of the frame
+        culled = stc.background_waves > beyond or stc.render_kernel == 2
+        culled_cases += culled
+        culled_by_kind[kind] += culled
+        tag = "%s case %d: %s %dx%d depth %d %s" % (scene, k, kind, W, H, depth, kw)
+        assert stc.rays == stn.rays and (stc.hits, stc.misses, stc.terminal_hits, stc.tir) == (stn.hits, stn.misses, stn.terminal_hits, stn.tir), tag
+        for f in range(depth):
+            assert np.array_equal(fc[f][0], fn[f][0]), tag
+            assert np.array_equal(fc[f][1].view(np.uint32), fn[f][1].view(np.uint32)), tag
+        if W * H <= 40000 and k % 4 == 0:       # the oracle on the same constants (path-weight mode: the kernel's summation order)
+            M, cam = cams[0][1].reshape(16), cams[0][2]
+            pw = s.render(M, cam, W, H, O.default_params(use_bvh=1, accum_mode=1, **kw))
+            ok = np.isfinite(pw["rgb"]).all()
+            if ok:
+                assert np.array_equal(fc[0][1][..., :3].view(np.uint32), pw["rgb"].view(np.uint32)), tag
+            assert np.array_equal(fc[0][0], pw["rgba8"]), tag
+            oracle_cases += 1
+    # the comparison only means something where the culled branch really ran: in a fifth of the cases at least, and for every
+    # kind of constants that leaves the scene in front of the camera (fov, distance, skew, mirrored)
+    assert culled_cases >= n_cases // 5, "the culled branch ran in only %d of %d cases: %s" % (culled_cases, n_cases, culled_by_kind)
+    for kind in ("fov", "radius", "skew", "mirror"):
+        assert culled_by_kind[kind] >= 3, culled_by_kind
+    assert oracle_cases >= 10
+
+
 # ------------------------------------------------------------------------------- sharding
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_tiles_reassemble_to_the_single_gpu_frame(gpu, world):

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), "librrdxr.so lacks %s declared in include/rrdxr.h" % n
     # and the binding table covers the header exactly
     assert sorted(_capi.SYMBOLS) == names
-    assert rr.lib().rr_abi_version() == 2
+    assert rr.lib().rr_abi_version() == 3
 
 
 def test_header_compiles_as_c_and_structs_have_the_documented_sizes(tmp_path):
