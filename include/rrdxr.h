@@ -106,7 +106,8 @@ typedef struct rr_stats {
     uint32_t bvh_depth;           /* deepest BLAS / TLAS leaf */
     uint32_t render_kernel;       /* which kernel rendered the last dispatch: 0 k_render_fused (one lane per pixel, nodes through
                                      the L1), 1 k_render_lds (the same with persistent workgroups and the nodes in LDS),
-                                     2 k_render_paths (four lanes per pixel); all three produce the same bits */
+                                     2 k_render_paths (four lanes per pixel), 7 k_stream_* (two-level scenes: one kernel per ray
+                                     generation, rays in HBM queues); all of them produce the same bits */
     /* wave-level loop trips of the RR_DISPATCH_COLLECT_STATS kernels: a 64-lane wave issues one internal-node step, one
      * triangle test or one shading pass per trip however many of its lanes take part, so these are what vector-issue
      * time is made of; node_visits / (64 * node_trips) is the lane utilisation of the internal-node phase, and so on */

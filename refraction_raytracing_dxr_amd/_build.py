@@ -11,7 +11,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "librrdxr.so")
 DEMO = os.path.join(PKG, "rrdemo")
 
-DEVICE_SOURCES = ["rr_bvh_build.hip", "rr_render.hip"]
+DEVICE_SOURCES = ["rr_bvh_build.hip", "rr_render.hip", "rr_render_stream.hip"]
 # RR_EXPERIMENTAL=1: also build the render-kernel experiments (rr_render_exp.hip: lane-asynchronous, queue-per-bounce and
 # pixel-refill renderers, selected at run time with RR_DEBUG_KERNEL); the product library does not contain them
 EXPERIMENTAL = os.environ.get("RR_EXPERIMENTAL") == "1"

@@ -160,12 +160,13 @@ struct rr_context {
     uint32_t* d_tickets = nullptr;   // k_render_lds ticket words: one block per stream a launch can be on (lanes, then the context's stream)
 
     // diagnostics switches, read once at rr_create (never needed for correct results)
-    int  dbg_kernel = 0;             // RR_DEBUG_KERNEL: 0 default, 1 "fused" (never the LDS kernel), 2 "async", 3 "wavefront", 4 "lds" (at every depth)
+    int  dbg_kernel = 0;             // RR_DEBUG_KERNEL: 0 default, 1 "fused" (never the LDS kernel), 2 "async", 3 "wavefront", 4 "lds" (at every depth), 10 "stream"
     int  dbg_stack = 0;              // RR_DEBUG_STACK
     int  dbg_ticket_blocks = 0;      // RR_DEBUG_TICKET: 1 = k_render_lds treats the whole frame as the mesh rectangle, 2 = no rectangle
+    bool dbg_async_set = false;
     uint32_t dbg_async[2] = { 2, 2 };    // RR_DEBUG_ASYNC="leaf,shade": thresholds of k_render_scene_async in eighths (rr_types.h)
     bool dbg_tile_order = true;      // RR_DEBUG_TILE_ORDER=0: tiles in image order (DispatchDev::rt_*)
-    int  dbg_stream_waves = 7;       // RR_DEBUG_STREAM_WAVES: waves per SIMD k_render_scene_stream is built for (5..7)
+    int  dbg_stream_waves = 6;       // RR_DEBUG_STREAM_WAVES: waves per SIMD k_render_scene_stream is built for (5..7)
     bool dbg_tlas32 = false;         // RR_DEBUG_TLAS32: two-level scenes keep 32-bit stack entries and register-parked rays
     int  dbg_shape = 0;              // RR_DEBUG_SHAPE: first k_render_lds workgroup shape to consider (rr_launch.h)
     std::string dbg_diag;            // RR_DEBUG_DIAG: file that receives per-wave diagnostics of Depth-1 dispatches
@@ -178,6 +179,26 @@ struct rr_context {
     // experimental queue-per-bounce renderer (RR_DEBUG_KERNEL=wavefront)
     WfBuffers wf = { { nullptr, nullptr }, nullptr, nullptr, nullptr, 0 };
     size_t    wf_pixels = 0;
+
+    // k_stream_* (rr_render_stream.hip): ray queues, leaf slots and pixel marks of one pass; grown on demand, never shrunk
+    StreamDev strm = { { nullptr, nullptr }, { nullptr, nullptr }, nullptr, nullptr, nullptr, nullptr, 0, 0 };
+    size_t    strm_cap = 0;          // queue entries allocated (each of the two queues)
+    size_t    strm_pixels = 0;       // pixel ordinals the slots / marks are allocated for
+    // Which of two kernels renders a class of launches is MEASURED, once per scene and launch shape: the scene's first dispatch of
+    // a class runs on the default kernel (clocks come up), the second is rendered by both candidates, each bracketed by HIP events
+    // (the frames are bit-identical, the dispatch just costs two extra launches), and the faster renders every later one.
+    // rr_build_tlas and a change of the launch shape (frame size, bounce limits, a rectangle share that doubles or halves) start
+    // the measurement afresh.  Classes: two-level scenes (k_render_fused / k_stream_*), launches of many slices of the
+    // reference's scene (k_render_fused / k_render_lds), launches of one or two slices (k_render_fused / k_render_paths).
+    struct KernelChoice {
+        int choice = 0;              // 0 undecided, 1 candidate A (k_render_fused), 2 candidate B
+        uint32_t seen = 0;
+        unsigned long long key = 0;  // the launch shape the choice was measured for
+        double share = 0.0;          // rectangle share of the frame at the measurement
+        float ms[2] = { 0.0f, 0.0f };
+    };
+    KernelChoice ch_tlas, ch_many, ch_few;
+    hipEvent_t ch_ev[4] = {};
 
     // trace_rays scratch
     rr_ray_dev* d_rays = nullptr;
@@ -364,14 +385,14 @@ int rr_create(int device_ordinal, rr_context** out)
     (void)hipMemsetAsync(ctx->d_cnt, 0, sizeof(CounterBlock), ctx->stream);
     (void)hipMemsetAsync(ctx->d_tickets, 0, (rr_context::MAX_LANES + 1) * LDS_TICKET_WORDS * sizeof(uint32_t), ctx->stream);   // the kernel leaves them zero
     if (const char* e = getenv("RR_DEBUG_KERNEL"))
-        ctx->dbg_kernel = !strcmp(e, "fused") ? 1 : !strcmp(e, "async") ? 2 : !strcmp(e, "wavefront") ? 3 : !strcmp(e, "lds") ? 4 : !strcmp(e, "paths") ? 5 : !strcmp(e, "refill") ? 6 : !strcmp(e, "scene-async") ? 8 : !strcmp(e, "scene-stream") ? 9 : 0;
+        ctx->dbg_kernel = !strcmp(e, "fused") ? 1 : !strcmp(e, "async") ? 2 : !strcmp(e, "wavefront") ? 3 : !strcmp(e, "lds") ? 4 : !strcmp(e, "paths") ? 5 : !strcmp(e, "refill") ? 6 : !strcmp(e, "scene-async") ? 8 : !strcmp(e, "scene-stream") ? 9 : !strcmp(e, "stream") ? 10 : 0;
     if (const char* e = getenv("RR_DEBUG_STACK")) ctx->dbg_stack = atoi(e);
     if (const char* e = getenv("RR_DEBUG_TICKET")) ctx->dbg_ticket_blocks = atoi(e);
     if (const char* e = getenv("RR_DEBUG_SHAPE")) ctx->dbg_shape = atoi(e);
     if (const char* e = getenv("RR_DEBUG_TLAS32")) ctx->dbg_tlas32 = atoi(e) != 0;
     if (const char* e = getenv("RR_DEBUG_STREAM_WAVES")) ctx->dbg_stream_waves = atoi(e);
     if (const char* e = getenv("RR_DEBUG_TILE_ORDER")) ctx->dbg_tile_order = atoi(e) != 0;
-    if (const char* e = getenv("RR_DEBUG_ASYNC")) { unsigned l = 2, sh = 2; if (sscanf(e, "%u,%u", &l, &sh) == 2 && l >= 1 && sh >= 1) { ctx->dbg_async[0] = l; ctx->dbg_async[1] = sh; } }
+    if (const char* e = getenv("RR_DEBUG_ASYNC")) { unsigned l = 2, sh = 2; if (sscanf(e, "%u,%u", &l, &sh) == 2 && l >= 1 && sh >= 1) { ctx->dbg_async[0] = l; ctx->dbg_async[1] = sh; ctx->dbg_async_set = true; } }
     if (const char* e = getenv("RR_DEBUG_DIAG")) ctx->dbg_diag = e;
     *out = ctx;
     return RR_OK;
@@ -393,6 +414,8 @@ int rr_destroy(rr_context* ctx)
     for (MeshRes& m : ctx->meshes) { dfree(m.d_verts); dfree(m.d_idx); dfree(m.nodes); dfree(m.qnodes); dfree(m.tris); dfree(m.nrms); }
     dfree(ctx->d_env); dfree(ctx->d_insts); dfree(ctx->d_pool_nodes); dfree(ctx->d_pool_qnodes); dfree(ctx->d_pool_tris); dfree(ctx->d_pool_nrms); dfree(ctx->d_rgba8); dfree(ctx->d_f32);
     dfree(ctx->wf.q[0]); dfree(ctx->wf.q[1]); dfree(ctx->wf.slots); dfree(ctx->wf.hit_list); dfree(ctx->wf.counts);
+    dfree(ctx->strm.q[0]); dfree(ctx->strm.q[1]); dfree(ctx->strm.fill[0]); dfree(ctx->strm.fill[1]); dfree(ctx->strm.heads); dfree(ctx->strm.slots); dfree(ctx->strm.pending);
+    for (hipEvent_t e : ctx->ch_ev) if (e) (void)hipEventDestroy(e);
     dfree(ctx->d_assembled); dfree(ctx->d_cnt); dfree(ctx->d_tickets); dfree(ctx->d_screen);
     for (uint32_t l = 0; l <= rr_context::MAX_LANES; ++l) dfree(ctx->d_park[l]); dfree(ctx->d_rays); dfree(ctx->d_hits); dfree(ctx->d_cams);
     for (int k = 0; k < rr_context::CAM_SLOTS; ++k) { if (ctx->h_cams[k]) (void)hipHostFree(ctx->h_cams[k]); if (ctx->h_cams_ev[k]) (void)hipEventDestroy(ctx->h_cams_ev[k]); }
@@ -657,6 +680,7 @@ int rr_build_tlas(rr_context* ctx, const rr_instance_desc* instances, uint32_t n
     ctx->single_identity = n == 1 && host[0].identity && (d0.hitgroup_flags >> 24) == 0 && ((d0.instance_id_mask >> 24) & 0xffu) != 0;
     if (scene_stack_need(ctx) > 64) return fail(ctx, RR_ERR_UNSUPPORTED, "rr_build_tlas: TLAS+BLAS deeper than the 64-entry stack");
     ctx->tlas_built = true;
+    ctx->ch_tlas = rr_context::KernelChoice(); ctx->ch_many = rr_context::KernelChoice(); ctx->ch_few = rr_context::KernelChoice();      // a new scene: the kernels are chosen afresh
     return RR_OK;
 }
 
@@ -798,6 +822,93 @@ void mesh_screen_rect(const float box[6], const rr_scene_constants* cams, uint32
     r[0] = lo8(x0, W8); r[1] = lo8(y0, H8); r[2] = hi8(x1, W8); r[3] = hi8(y1, H8);
 }
 
+// ---- k_stream_* : buffers and passes ----------------------------------------------------------------------------------
+// One pass renders `fc` consecutive slices of the dispatch.  Worst case per pixel of the ray kernels' blocks: four rays alive in
+// one generation (max_reflect <= 2), so a queue holds 4 x pixels entries plus what the waves' 1 024-entry reservations can
+// leave unused; slots are 64 B and the mark 1 B per pixel.  A pass is sized to stay inside STREAM_BUDGET bytes (288 GB of HBM:
+// the buffers are kept for the life of the context).
+constexpr size_t STREAM_BUDGET = (size_t)12 << 30;
+constexpr uint32_t STREAM_BLK = 1024;
+
+struct StreamPlan { uint32_t fc, n_wg; size_t cap, pixels; };
+
+StreamPlan stream_plan(const rr_context* ctx, const DispatchDev& a, uint32_t depth)
+{
+    auto rect_wb = [&](uint32_t frames) -> size_t {
+        const size_t all = (size_t)a.blocks_per_frame * frames * 4u;
+        if (a.rt_w == 0u) return all;
+        const size_t groups = ((size_t)a.rt_w * a.rt_h + 7u) / 8u;
+        return std::min(all, groups * 128u * frames);
+    };
+    auto bytes = [&](uint32_t frames, StreamPlan& pl) -> size_t {
+        const size_t wb = rect_wb(frames);
+        pl.pixels = wb * 64u;
+        pl.n_wg = (uint32_t)std::min<size_t>((size_t)ctx->n_cus * 8u, std::max<size_t>(1u, (wb + 15u) / 16u));
+        pl.cap = ((4u * pl.pixels + (size_t)pl.n_wg * 4u * STREAM_BLK + STREAM_BLK - 1u) / STREAM_BLK) * STREAM_BLK;
+        return 2u * pl.cap * 48u + 2u * (pl.cap / 64u) * 4u + pl.pixels * 65u;
+    };
+    StreamPlan pl{ 1, 1, 0, 0 };
+    uint32_t fc = depth;
+    while (fc > 1u && bytes(fc, pl) > STREAM_BUDGET) fc = (fc + 1u) / 2u;
+    (void)bytes(fc, pl);
+    pl.fc = fc;
+    return pl;
+}
+
+int ensure_stream_buffers(rr_context* ctx, const StreamPlan& pl)
+{
+    if (pl.cap > 0xffffffffull || pl.pixels > 0xffffffffull) return fail(ctx, RR_ERR_UNSUPPORTED, "stream renderer: pass too large for 32-bit ray indices");
+    if (!ctx->strm.heads) {      // head counters and, behind them, the chunk ticket counters: one block, zeroed by one memset per pass
+        RR_HIP(hipMalloc(&ctx->strm.heads, (STREAM_MAX_GEN + STREAM_MAX_GEN * 8u * 16u) * sizeof(uint32_t)));
+        ctx->strm.next = ctx->strm.heads + STREAM_MAX_GEN;
+    }
+    if (pl.cap > ctx->strm_cap) {
+        RR_HIP(hipDeviceSynchronize());
+        dfree(ctx->strm.q[0]); dfree(ctx->strm.q[1]); dfree(ctx->strm.fill[0]); dfree(ctx->strm.fill[1]);
+        ctx->strm_cap = 0;
+        for (int k = 0; k < 2; ++k) {
+            RR_HIP(hipMalloc(&ctx->strm.q[k], pl.cap * 48u));
+            RR_HIP(hipMalloc(&ctx->strm.fill[k], (pl.cap / 64u) * 4u));
+        }
+        ctx->strm_cap = pl.cap;
+    }
+    if (pl.pixels > ctx->strm_pixels) {
+        RR_HIP(hipDeviceSynchronize());
+        dfree(ctx->strm.slots); dfree(ctx->strm.pending);
+        ctx->strm_pixels = 0;
+        RR_HIP(hipMalloc(&ctx->strm.slots, pl.pixels * 64u));
+        RR_HIP(hipMalloc(&ctx->strm.pending, pl.pixels));
+        ctx->strm_pixels = pl.pixels;
+    }
+    return RR_OK;
+}
+
+// the whole dispatch through the generation-per-kernel renderer, `fc` slices per pass
+int render_stream(rr_context* ctx, const SceneDev& sc, const DispatchDev& a, uint32_t depth, int need, bool stats, bool rgb8)
+{
+    const StreamPlan pl = stream_plan(ctx, a, depth);
+    if (int r = ensure_stream_buffers(ctx, pl)) return r;
+    for (uint32_t f0 = 0; f0 < depth; f0 += pl.fc) {
+        const uint32_t fc = std::min(pl.fc, depth - f0);
+        DispatchDev b = a;
+        // lanes (in eighths of the wave's live lanes) a step / a shading pass needs to be issued: 1 and 3 measured best on the
+        // 1 024-instance scene (tools/exp_stream_sweep.sh; RR_DEBUG_ASYNC overrides)
+        if (!ctx->dbg_async_set) { b.async_leaf_num = 1u; b.async_shade_num = 3u; }
+        b.cams = a.cams + f0;
+        b.n_frames = fc;
+        b.n_blocks = a.blocks_per_frame * fc;
+        b.out_rgba8 = a.out_rgba8 + (size_t)f0 * a.frame_stride;
+        if (a.out_f32) b.out_f32 = a.out_f32 + (size_t)f0 * a.frame_stride;
+        StreamDev s = ctx->strm;
+        s.cap = (uint32_t)ctx->strm_cap;
+        const size_t all = (size_t)b.n_blocks * 4u;
+        s.n_rect_wb = (uint32_t)(a.rt_w == 0u ? all : std::min(all, (((size_t)a.rt_w * a.rt_h + 7u) / 8u) * 128u * fc));
+        RR_HIP(launch_render_stream(sc, b, s, need, pl.n_wg, stats, ctx->stream, ctx->dbg_stream_waves));
+    }
+    (void)rgb8;
+    return RR_OK;
+}
+
 inline bool timed_request(const rr_dispatch_params& p) { return (p.flags & RR_DISPATCH_TIME_KERNEL) != 0; }
 
 // out_slot: which of the frames_in_flight output regions of the internal frame buffer this dispatch writes;
@@ -890,21 +1001,10 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     const bool stats = (p.flags & RR_DISPATCH_COLLECT_STATS) != 0;
     const uint32_t need = scene_stack_need(ctx);
     const bool keep = keep_counters || (p.flags & RR_DISPATCH_KEEP_COUNTERS) != 0;
-    if (!keep) RR_HIP(hipMemsetAsync(ctx->d_cnt, 0, sizeof(CounterBlock), ctx->stream));
     if (compact && local < max_local)            // keep the gathered tail deterministic
         for (uint32_t f = 0; f < depth; ++f)
             RR_HIP(hipMemsetAsync(reinterpret_cast<uint8_t*>(a.out_rgba8 + f * stride) + (size_t)local * TILE * TILE * (rgb8 ? 3 : 4), 0,
                                   (size_t)(max_local - local) * TILE * TILE * (rgb8 ? 3 : 4), ctx->stream));
-    const bool timed = (p.flags & RR_DISPATCH_TIME_KERNEL) != 0;
-    if (timed) {
-        if (ctx->kev_used >= 4096) return fail(ctx, RR_ERR_STATE, "dispatch: 4096 timed dispatches pending, call rr_kernel_time");
-        while (ctx->kev.size() < (size_t)(ctx->kev_used + 1) * 2) {
-            hipEvent_t e;
-            RR_HIP(hipEventCreate(&e));
-            ctx->kev.push_back(e);
-        }
-        RR_HIP(hipEventRecord(ctx->kev[(size_t)ctx->kev_used * 2], ctx->stream));
-    }
     int stack_sel = need <= 19 ? 19 : need <= 22 ? 22 : need <= 26 ? 26 : need <= 31 ? 31 : need <= 39 ? 39 : 64;     // rr_render.hip: sizes that fill the LDS with 6 / 5 / 4 / 2 workgroups
 #ifdef RR_EXPERIMENTAL
     const bool wavefront = ctx->dbg_kernel == 3 && ctx->single_identity && !compact && !want_f32 && !stats && p.max_reflect <= 2 && p.max_refract < 62;
@@ -940,15 +1040,12 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     // measures within 1-3 % of k_render_fused either way (monkey.obj Depth 64: 5.71 against 5.68 ms per launch); it is kept
     // behind RR_DEBUG_KERNEL=lds, for the parity tests and for experiments, and never chosen by itself.
     const bool lds_fits = m0 && ctx->dbg_stack == 0 && m0->n_tris < 32768u && lds_kernel_shape(node_bytes, need + 1, nullptr, ctx->dbg_shape) >= 0;
-    bool lds_kernel = lds_fits && ctx->dbg_kernel == 4;
     // Launches of one or two slices whose scene is small on screen last as long as their most expensive wave: there the
     // path-parallel kernel (four lanes per pixel inside the scene's screen rectangle: a fifth of the longest chain of
     // dependent rays, four waves per block) wins -- monkey.obj 1080p Depth 1: 268 us against 471, ott.obj 626 against 1 419.
     // It traces the primary ray four times and the count-1 rays twice, so where the mesh fills the frame and the launch is
     // bound by throughput it loses (sphere.obj 483 us against 263, shell.obj 606 against 348): those stay with k_render_fused.
     const bool have_rect = a.hx1 > a.hx0 && a.hy1 > a.hy0;
-    const bool paths_kernel = (ctx->dbg_kernel == 5 || (ctx->dbg_kernel == 0 && depth <= 2 && rect_share < 0.25)) && !compact && ctx->tile_world == 1 &&
-                              p.max_reflect <= 2 && need <= 39 && ctx->dbg_stack == 0 && have_rect;
     uint32_t pool_nodes = 0;
     if (!ctx->single_identity) {
         pool_nodes = ctx->n_insts > 1 ? ctx->n_insts - 1 : 1;
@@ -962,23 +1059,31 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
                                                      : (pool_nodes < 32768u && ctx->n_pool_tris + ctx->n_insts < 32768u);
     // (experiment, RR_DEBUG_KERNEL=scene-async: the lane-asynchronous kernel for scenes with a TLAS, see rr_render_exp.hip)
     const bool scene_stream = ctx->dbg_kernel == 9 && !ctx->single_identity && p.max_reflect <= 2 && need <= 30 && refill_stack16 && !compact && !a.diag &&
-                              ctx->dbg_stack == 0 && !paths_kernel;
-    const bool scene_async = ctx->dbg_kernel == 8 && !ctx->single_identity && p.max_reflect <= 2 && need <= 39 && !a.diag && ctx->dbg_stack == 0 && !paths_kernel;
+                              ctx->dbg_stack == 0;
+    const bool scene_async = ctx->dbg_kernel == 8 && !ctx->single_identity && p.max_reflect <= 2 && need <= 39 && !a.diag && ctx->dbg_stack == 0;
     // (experiment, RR_DEBUG_KERNEL=refill: on the 1 024-monkey grid it raises the share of live lanes per shading pass from
     // 54 % to 80 % and the frame time from 8.9 to 10.8 ms -- a pass lasts as long as its longest ray either way, and with
     // every lane alive that one is longer)
-    const bool refill_kernel = ctx->dbg_kernel == 6 && p.max_reflect <= 2 && need <= 39 && !a.diag && ctx->dbg_stack == 0 && !paths_kernel;
-#ifdef RR_EXPERIMENTAL
-    if (wavefront) RR_HIP(launch_render_wavefront(sc, a, ctx->wf, stack_sel, ctx->stream));
-    else if (refill_kernel) RR_HIP(launch_render_refill(sc, a, (int)need, stats, ctx->stream, refill_stack16));
-    else if (scene_async) RR_HIP(launch_render_scene_async(sc, a, (int)need, stats, ctx->stream, refill_stack16));
-    else if (scene_stream) RR_HIP(launch_render_scene_stream(sc, a, ctx->d_tickets + (size_t)rr_context::MAX_LANES * LDS_TICKET_WORDS, ctx->n_cus,
-                                                             ctx->dbg_stream_waves, stats, ctx->stream));
-    else if (ctx->dbg_kernel == 2 && ctx->single_identity) RR_HIP(launch_render_async(sc, a, stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream));
-    else
-#endif
-    if (paths_kernel) RR_HIP(launch_render_paths(sc, a, (int)need, stats, ctx->stream));
-    else if (lds_kernel) {
+    const bool refill_kernel = ctx->dbg_kernel == 6 && p.max_reflect <= 2 && need <= 39 && !a.diag && ctx->dbg_stack == 0;
+    // ---- the candidates
+    const bool stream_ok = !ctx->single_identity && p.max_reflect <= 2 && p.max_refract <= (int)STREAM_MAX_GEN - 2 && refill_stack16 && need <= 39 &&
+                           !a.diag && ctx->dbg_stack == 0 && !scene_stream && !scene_async && !refill_kernel && !ctx->dbg_tlas32;
+    const bool paths_ok = !compact && ctx->tile_world == 1 && p.max_reflect <= 2 && need <= 39 && ctx->dbg_stack == 0 && have_rect && depth <= 2;
+    auto launch_fused = [&](bool st) -> int {
+        // deep trees of small meshes: 16-bit stack entries keep eight waves per SIMD (LDS would otherwise allow 6/5/4)
+        bool stack16 = ctx->single_identity && need > 19 && need <= 39 && ctx->dbg_stack == 0 &&
+                       ctx->meshes[(size_t)ctx->inst_host[0].blas].n_tris < 32768u;
+        // two-level scenes: 16-bit entries wherever every node / leaf reference of the pool fits them (RR_DEBUG_TLAS32=1: never)
+        if (!ctx->single_identity && refill_stack16 && (need <= 30 || (need <= 39 && depth > 2)) && p.max_reflect <= 2 && ctx->dbg_stack == 0 && !ctx->dbg_tlas32) stack16 = true;
+        // (launches of one or two slices used to take the five-wave build, whose long waves ran faster without the spills of the
+        // 6..8-wave builds; since the background branch left those builds with six spilled words the ladder above is the faster one
+        // at every depth: sphere.obj Depth 1 250 us against 268, monkey.obj and shell.obj equal)
+        if (depth <= 2 && ctx->single_identity) stack16 = false;
+        // (the two-level 16-bit-stack builds are sized by the tree itself: 30 entries still leave five workgroups per CU)
+        RR_HIP(launch_render_fused(sc, a, !ctx->single_identity && stack16 && ctx->dbg_stack == 0 ? (int)need : stack_sel, p.max_reflect <= 2 ? 2 : 8, st, ctx->stream, stack16));
+        return RR_OK;
+    };
+    auto launch_lds = [&](bool st) -> int {
         LdsDispatch q;
         memset(&q, 0, sizeof q);
         uint32_t slot = rr_context::MAX_LANES;          // launches on one stream are ordered: one ticket block per stream
@@ -995,7 +1100,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         }
         q.park = ctx->d_park[slot];
         uint32_t rect[4];
-        mesh_screen_rect(m0->bounds, (ctx->dbg_ticket_blocks & 3) == 1 ? nullptr : h_cams, depth, width, height, rect);
+        mesh_screen_rect(m0->bounds, ((ctx->dbg_ticket_blocks & 3) == 1 || (p.flags & RR_DISPATCH_DEBUG_NO_CULL)) ? nullptr : h_cams, depth, width, height, rect);
         // experiments (RR_DEBUG_TICKET): low bits 1 = whole frame in phase 1, 2 = no phase 1, 3 = phase 1 at every depth;
         // +16: eight queues, a wave starts on its XCD's; +32: parked rays in registers
         const int tk = ctx->dbg_ticket_blocks & 3;
@@ -1004,24 +1109,82 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         // (monkey.obj Depth 64: 90 us per frame, 104 with 32 queues entered by wave number)
         q.n_queues = (ctx->dbg_ticket_blocks & 64) ? 64u : (ctx->dbg_ticket_blocks & 128) ? LDS_QUEUES : 8u;   // launch_render_lds caps it at the grid size
         q.home_xcc = (ctx->dbg_ticket_blocks & 16) ? 0u : 1u;
-
         q.rx0 = rect[0]; q.ry0 = rect[1]; q.rx1 = rect[2]; q.ry1 = rect[3];
         q.node_bytes = node_bytes;
         q.stack_entries = need + 1;                     // the tree's depth bounds the stack; one entry to spare
-        RR_HIP(launch_render_lds(sc, a, q, ctx->n_cus, stats, ctx->stream, ctx->dbg_shape));
-    } else {
-        // deep trees of small meshes: 16-bit stack entries keep eight waves per SIMD (LDS would otherwise allow 6/5/4)
-        bool stack16 = ctx->single_identity && need > 19 && need <= 39 && ctx->dbg_stack == 0 &&
-                       ctx->meshes[(size_t)ctx->inst_host[0].blas].n_tris < 32768u;
-        // two-level scenes: 16-bit entries wherever every node / leaf reference of the pool fits them (RR_DEBUG_TLAS32=1: never)
-        if (!ctx->single_identity && refill_stack16 && (need <= 30 || (need <= 39 && depth > 2)) && p.max_reflect <= 2 && ctx->dbg_stack == 0 && !ctx->dbg_tlas32) stack16 = true;
-        // (launches of one or two slices used to take the five-wave build, whose long waves ran faster without the spills of the
-        // 6..8-wave builds; since the background branch left those builds with six spilled words the ladder above is the faster one
-        // at every depth: sphere.obj Depth 1 250 us against 268, monkey.obj and shell.obj equal)
-        if (depth <= 2 && ctx->single_identity) stack16 = false;
-        // (the two-level 16-bit-stack builds are sized by the tree itself: 30 entries still leave five workgroups per CU)
-        RR_HIP(launch_render_fused(sc, a, !ctx->single_identity && stack16 && ctx->dbg_stack == 0 ? (int)need : stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream, stack16));
+        RR_HIP(launch_render_lds(sc, a, q, ctx->n_cus, st, ctx->stream, ctx->dbg_shape));
+        return RR_OK;
+    };
+    auto launch_paths = [&](bool st) -> int { RR_HIP(launch_render_paths(sc, a, (int)need, st, ctx->stream)); return RR_OK; };
+    auto launch_stream = [&](bool st) -> int { return render_stream(ctx, sc, a, depth, (int)need, st, rgb8); };
+
+    // ---- which kernel: forced by RR_DEBUG_KERNEL, or the class's measured choice
+    enum { K_FUSED = 0, K_LDS = 1, K_PATHS = 2, K_STREAM = 7 };
+    int kernel = K_FUSED;
+    rr_context::KernelChoice* ch = nullptr;             // the class this launch belongs to, if it has two candidates
+    int cand_b = K_FUSED;
+    if (ctx->dbg_kernel == 10) { if (stream_ok) kernel = K_STREAM; }
+    else if (ctx->dbg_kernel == 5) { if (paths_ok) kernel = K_PATHS; }
+    else if (ctx->dbg_kernel == 4) { if (lds_fits) kernel = K_LDS; }
+    else if (ctx->dbg_kernel == 0 && !a.diag) {
+        if (stream_ok) { ch = &ctx->ch_tlas; cand_b = K_STREAM; }
+        else if (paths_ok) { ch = &ctx->ch_few; cand_b = K_PATHS; }
+        else if (lds_fits && depth >= 3 && !compact) { ch = &ctx->ch_many; cand_b = K_LDS; }
     }
+    if (a.diag && paths_ok && rect_share < 0.25 && ctx->dbg_kernel == 0) kernel = K_PATHS;      // (the diagnostic builds keep round 2's rule)
+    if (ch) {
+        const unsigned long long key = ((unsigned long long)width << 48) ^ ((unsigned long long)height << 32) ^ ((unsigned long long)(uint32_t)p.max_refract << 8) ^
+                                       ((unsigned long long)(uint32_t)p.max_reflect << 4) ^ (depth <= 2 ? depth : depth < 16 ? 3u : 4u);
+        if (ch->choice != 0 && (ch->key != key || rect_share > 2.0 * ch->share || rect_share * 2.0 < ch->share)) *ch = rr_context::KernelChoice();
+        if (ch->choice == 0 && !keep && !(p.flags & RR_DISPATCH_DEBUG_NO_CULL)) {
+            if (ch->key != key) { ch->key = key; ch->seen = 0; }
+            if (ch->seen++ >= 1u) {
+                // the measurement: both candidates render this dispatch (product builds), one after the other
+                if (cand_b == K_STREAM) if (int r = ensure_stream_buffers(ctx, stream_plan(ctx, a, depth))) return r;
+                for (int k = 0; k < 4; ++k) if (!ctx->ch_ev[k]) RR_HIP(hipEventCreate(&ctx->ch_ev[k]));
+                for (int c = 0; c < 2; ++c) {
+                    RR_HIP(hipEventRecord(ctx->ch_ev[2 * c], ctx->stream));
+                    int r = c == 0 ? launch_fused(false) : cand_b == K_STREAM ? launch_stream(false) : cand_b == K_PATHS ? launch_paths(false) : launch_lds(false);
+                    if (r) return r;
+                    RR_HIP(hipEventRecord(ctx->ch_ev[2 * c + 1], ctx->stream));
+                }
+                RR_HIP(hipEventSynchronize(ctx->ch_ev[3]));
+                RR_HIP(hipEventElapsedTime(&ch->ms[0], ctx->ch_ev[0], ctx->ch_ev[1]));
+                RR_HIP(hipEventElapsedTime(&ch->ms[1], ctx->ch_ev[2], ctx->ch_ev[3]));
+                ch->choice = ch->ms[1] < ch->ms[0] ? 2 : 1;
+                ch->share = rect_share;
+            }
+        }
+        kernel = ch->choice == 2 ? cand_b : K_FUSED;
+        // (until the measurement: the round-2 rule for launches of one or two slices -- the path-parallel kernel where the scene is small on screen)
+        if (ch->choice == 0 && cand_b == K_PATHS && rect_share < 0.25) kernel = K_PATHS;
+    }
+    const bool stream_kernel = kernel == K_STREAM, paths_kernel = kernel == K_PATHS, lds_kernel = kernel == K_LDS;
+
+    if (!keep) RR_HIP(hipMemsetAsync(ctx->d_cnt, 0, sizeof(CounterBlock), ctx->stream));      // (also what a measurement above counted)
+    const bool timed = (p.flags & RR_DISPATCH_TIME_KERNEL) != 0;
+    if (timed) {
+        if (ctx->kev_used >= 4096) return fail(ctx, RR_ERR_STATE, "dispatch: 4096 timed dispatches pending, call rr_kernel_time");
+        while (ctx->kev.size() < (size_t)(ctx->kev_used + 1) * 2) {
+            hipEvent_t e;
+            RR_HIP(hipEventCreate(&e));
+            ctx->kev.push_back(e);
+        }
+        RR_HIP(hipEventRecord(ctx->kev[(size_t)ctx->kev_used * 2], ctx->stream));
+    }
+#ifdef RR_EXPERIMENTAL
+    if (wavefront) RR_HIP(launch_render_wavefront(sc, a, ctx->wf, stack_sel, ctx->stream));
+    else if (refill_kernel) RR_HIP(launch_render_refill(sc, a, (int)need, stats, ctx->stream, refill_stack16));
+    else if (scene_async) RR_HIP(launch_render_scene_async(sc, a, (int)need, stats, ctx->stream, refill_stack16));
+    else if (scene_stream) RR_HIP(launch_render_scene_stream(sc, a, ctx->d_tickets + (size_t)rr_context::MAX_LANES * LDS_TICKET_WORDS, ctx->n_cus,
+                                                             ctx->dbg_stream_waves, stats, ctx->stream));
+    else if (ctx->dbg_kernel == 2 && ctx->single_identity) RR_HIP(launch_render_async(sc, a, stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream));
+    else
+#endif
+    if (stream_kernel) { if (int r = launch_stream(stats)) return r; }
+    else if (paths_kernel) { if (int r = launch_paths(stats)) return r; }
+    else if (lds_kernel) { if (int r = launch_lds(stats)) return r; }
+    else { if (int r = launch_fused(stats)) return r; }
     if (timed) {
         RR_HIP(hipEventRecord(ctx->kev[(size_t)ctx->kev_used * 2 + 1], ctx->stream));
         ++ctx->kev_used;
@@ -1033,8 +1196,8 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         (void)hipFree(d_diag);
         if (FILE* f = fopen(diag_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
-    snprintf(ctx->last_kernel_name, sizeof ctx->last_kernel_name, "%s", (wavefront || refill_kernel || scene_async || scene_stream) ? "(experiment)" : last_render_kernel_name());
-    ctx->last_kernel = wavefront ? 3u : paths_kernel ? 2u : refill_kernel ? 4u : scene_async ? 5u : scene_stream ? 6u : lds_kernel ? 1u : 0u;
+    snprintf(ctx->last_kernel_name, sizeof ctx->last_kernel_name, "%s", stream_kernel ? last_stream_kernel_name() : (wavefront || refill_kernel || scene_async || scene_stream) ? "(experiment)" : last_render_kernel_name());
+    ctx->last_kernel = stream_kernel ? 7u : wavefront ? 3u : paths_kernel ? 2u : refill_kernel ? 4u : scene_async ? 5u : scene_stream ? 6u : lds_kernel ? 1u : 0u;
     ctx->W = width; ctx->H = height; ctx->frame_world = ctx->tile_world; ctx->frame_depth = depth;
     ctx->have_f32 = want_f32; ctx->have_frame = ext_tiles == nullptr; ctx->have_assembled = false;
     if (!ext_tiles) ctx->frame_base = out_base;

@@ -20,6 +20,9 @@ int lds_kernel_shape(uint32_t node_bytes, uint32_t stack_entries, size_t* lds_by
 hipError_t launch_render_lds(const SceneDev& sc, const DispatchDev& a, LdsDispatch q, int n_cus, bool stats, hipStream_t s, int min_shape = 0);
 // launches of one or two slices: four lanes per pixel inside the scene's screen rectangle (k_render_paths)
 hipError_t launch_render_paths(const SceneDev& sc, const DispatchDev& a, int stack, bool stats, hipStream_t s);
+// ---- rr_render_stream.hip: one kernel per ray generation, rays in HBM queues, lanes refilled as their rays end (two-level scenes)
+hipError_t launch_render_stream(const SceneDev& sc, const DispatchDev& a, const StreamDev& s, int stack, uint32_t n_wg, bool stats, hipStream_t st, int waves = 6);
+const char* last_stream_kernel_name();
 // the instantiation the calling thread's last launch_render_* call launched, e.g. "k_render_fused<19, 2, false, false, false, unsigned int, 0>"
 const char* last_render_kernel_name();
 hipError_t launch_trace_rays(const SceneDev& sc, const rr_ray_dev* rays, uint32_t n, rr_hit_dev* hits, uint32_t* err,

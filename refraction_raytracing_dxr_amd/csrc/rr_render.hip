@@ -341,10 +341,11 @@ __global__ __launch_bounds__(NW * 64, NW * WGS / 4) void k_render_lds(SceneDev s
         const unsigned long long dr0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
         const uint32_t dI0 = DIAG ? diag_tr[wave] : 0u, dL0 = DIAG ? diag_tr[16 + wave] : 0u, dS0 = DIAG ? diag_tr[32 + wave] : 0u;
         const uint32_t x = bp.x0 + lx, y = bp.y0 + ly;
+        const bool may_hit = bp.x0 + 8u > a.hx0 && bp.x0 < a.hx1 && bp.y0 + 8u > a.hy0 && bp.y0 < a.hy1;
+        if (STATS && !may_hit) st.bg_blocks += 1u;
         if (x < a.W && y < a.H) {
             const CamDev& cb = a.cams[bp.frame];
             st.pixels += 1;
-            const bool may_hit = bp.x0 + 8u > a.hx0 && bp.x0 < a.hx1 && bp.y0 + 8u > a.hy0 && bp.y0 < a.hy1;
             const f3 acc = render_pixel<STATS, false, DIAG, E, LdsNodes>(sc, a, cb, x, y, may_hit, stk, ns, park, st, Diag{ DIAG ? &diag_tr[wave] : nullptr, 16 });
             const size_t o = a.compact_out == 0u ? (size_t)y * a.W + x
                                                 : (size_t)bp.tile_local * (TILE * TILE) + (bp.py0 + ly) * TILE + (bp.px0 + lx);

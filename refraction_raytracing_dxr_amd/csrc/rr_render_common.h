@@ -249,7 +249,7 @@ __device__ __forceinline__ void flush_stats(const DispatchDev& a, const LaneStat
         v = wave_reduce_add(st.passes); if (lane == 0 && v) atomicAdd(&a.counters[C_PASSES], (unsigned long long)v);
         if (lane == 0 && st.blocks) atomicAdd(&a.counters[C_WAVES], (unsigned long long)st.blocks);
         if (lane == 0 && st.bg_blocks) atomicAdd(&a.counters[C_BG_WAVES], (unsigned long long)st.bg_blocks);
-        if (lane == 0 && st.blocks) {
+        if (lane == 0 && (st.blocks || st.rays)) {
             atomicAdd(&a.counters[C_CLK_TICKS], (unsigned long long)(__builtin_amdgcn_s_memtime() - st.clk0));
             atomicAdd(&a.counters[C_CLK_REAL], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - st.rt0));
         }

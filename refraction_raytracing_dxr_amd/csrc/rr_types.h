@@ -169,6 +169,20 @@ struct LdsDispatch {
 constexpr uint32_t LDS_QUEUES = 512;
 constexpr uint32_t LDS_TICKET_WORDS = (2 * LDS_QUEUES + 1) * 16;
 
+// k_stream_* (rr_render_stream.hip): the ray queues of one pass of the generation-per-kernel renderer
+constexpr uint32_t STREAM_MAX_GEN = 64;     // head counters: generations 0 .. max_refract + 1 <= 63
+struct StreamDev {
+    float4*   q[2];           // ray queues (generation g reads q[g & 1], writes q[(g + 1) & 1]): cap entries of 3 x float4
+    uint32_t* fill[2];        // rays in each 64-entry chunk of the queues' reserved blocks
+    uint32_t* heads;          // [STREAM_MAX_GEN]: entries reserved in the queue that FEEDS generation g (multiples of 1 024)
+    uint32_t* next;           // [STREAM_MAX_GEN][8][16]: chunk ticket counters of generation g's kernel, one per XCD, 64 B apart
+    float4*   slots;          // [n_rect_wb * 64][4]: (weight, texel) of a pixel's up to four leaves, in the recursion's order
+    uint8_t*  pending;        // [n_rect_wb * 64]: 1 = the pixel's colour is the sum of its slots (resolve), 0 = already stored
+    uint32_t  cap;            // entries per queue (a multiple of 1 024)
+    uint32_t  n_rect_wb;      // wave-blocks (8x8 pixel blocks, numbered as k_render_fused's) the ray kernels render; the rest
+                              // are background blocks (k_stream_background)
+};
+
 enum Counter : int {
     C_RAYS = 0, C_PRIMARY, C_SECONDARY, C_HITS, C_MISSES, C_TERMINAL, C_TIR, C_NODES, C_TRIS,
     C_NODE_TRIPS, C_LEAF_TRIPS, C_PASSES, C_WAVES,      // wave-level loop trips of the STATS builds (what the vector unit issues for)

@@ -775,10 +775,10 @@ def test_background_culling_equals_tracing_every_primary_ray(gpu, scene):
         (fc, stc), (fn, stn) = out
         # (8x8 blocks of the 32x32 tiles that lie beyond the frame's edge count as background blocks in both runs)
         beyond = (((W + 31) // 32) * ((H + 31) // 32) * 16 - ((W + 7) // 8) * ((H + 7) // 8)) * depth
-        assert stn.background_waves == beyond
-        # the culled branch ran: k_render_fused counted background blocks inside the frame, or the launch went to k_render_paths
-        # (render_kernel 2), which is only chosen where the rectangle is under a quarter of the frame
-        culled = stc.background_waves > beyond or stc.render_kernel == 2
+        assert stn.background_waves == beyond or stn.render_kernel == 2
+        # the culled branch ran: the kernel counted background blocks inside the frame, or the launch went to k_render_paths
+        # (render_kernel 2: it only ever renders the rectangle's blocks with TraceRay)
+        culled = stc.background_waves > beyond or (stc.render_kernel == 2 and stn.render_kernel != 2)
         culled_cases += culled
         culled_by_kind[kind] += culled
         tag = "%s case %d: %s %dx%d depth %d %s" % (scene, k, kind, W, H, depth, kw)
