@@ -163,6 +163,7 @@ struct rr_context {
     int  dbg_kernel = 0;             // RR_DEBUG_KERNEL: 0 default, 1 "fused" (never the LDS kernel), 2 "async", 3 "wavefront", 4 "lds" (at every depth), 10 "stream"
     int  dbg_stack = 0;              // RR_DEBUG_STACK
     int  dbg_ticket_blocks = 0;      // RR_DEBUG_TICKET: 1 = k_render_lds treats the whole frame as the mesh rectangle, 2 = no rectangle
+    bool dbg_group_trace = true;     // RR_DEBUG_GROUP_TRACE=0: k_render_paths never shares a ray between lanes
     bool dbg_async_set = false;
     uint32_t dbg_async[2] = { 2, 2 };    // RR_DEBUG_ASYNC="leaf,shade": thresholds of k_render_scene_async in eighths (rr_types.h)
     bool dbg_tile_order = true;      // RR_DEBUG_TILE_ORDER=0: tiles in image order (DispatchDev::rt_*)
@@ -394,6 +395,7 @@ int rr_create(int device_ordinal, rr_context** out)
     if (const char* e = getenv("RR_DEBUG_TILE_ORDER")) ctx->dbg_tile_order = atoi(e) != 0;
     if (const char* e = getenv("RR_DEBUG_ASYNC")) { unsigned l = 2, sh = 2; if (sscanf(e, "%u,%u", &l, &sh) == 2 && l >= 1 && sh >= 1) { ctx->dbg_async[0] = l; ctx->dbg_async[1] = sh; ctx->dbg_async_set = true; } }
     if (const char* e = getenv("RR_DEBUG_DIAG")) ctx->dbg_diag = e;
+    if (const char* e = getenv("RR_DEBUG_GROUP_TRACE")) ctx->dbg_group_trace = atoi(e) != 0;
     *out = ctx;
     return RR_OK;
 }
@@ -843,7 +845,7 @@ StreamPlan stream_plan(const rr_context* ctx, const DispatchDev& a, uint32_t dep
     auto bytes = [&](uint32_t frames, StreamPlan& pl) -> size_t {
         const size_t wb = rect_wb(frames);
         pl.pixels = wb * 64u;
-        pl.n_wg = (uint32_t)std::min<size_t>((size_t)ctx->n_cus * 8u, std::max<size_t>(1u, (wb + 15u) / 16u));
+        pl.n_wg = (uint32_t)std::min<size_t>((size_t)ctx->n_cus * 6u, std::max<size_t>(1u, (wb + 15u) / 16u));     // six workgroups of the ray kernels fit a CU
         pl.cap = ((4u * pl.pixels + (size_t)pl.n_wg * 4u * STREAM_BLK + STREAM_BLK - 1u) / STREAM_BLK) * STREAM_BLK;
         return 2u * pl.cap * 48u + 2u * (pl.cap / 64u) * 4u + pl.pixels * 65u;
     };
@@ -891,9 +893,9 @@ int render_stream(rr_context* ctx, const SceneDev& sc, const DispatchDev& a, uin
     for (uint32_t f0 = 0; f0 < depth; f0 += pl.fc) {
         const uint32_t fc = std::min(pl.fc, depth - f0);
         DispatchDev b = a;
-        // lanes (in eighths of the wave's live lanes) a step / a shading pass needs to be issued: 1 and 3 measured best on the
+        // lanes (in sixteenths of the wave's live lanes) a step / a shading pass needs to be issued: measured on the
         // 1 024-instance scene (tools/exp_stream_sweep.sh; RR_DEBUG_ASYNC overrides)
-        if (!ctx->dbg_async_set) { b.async_leaf_num = 1u; b.async_shade_num = 3u; }
+        if (!ctx->dbg_async_set) { b.async_leaf_num = 2u; b.async_shade_num = 6u; }
         b.cams = a.cams + f0;
         b.n_frames = fc;
         b.n_blocks = a.blocks_per_frame * fc;
@@ -954,6 +956,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     memset(&a, 0, sizeof a);
     a.sx = ctx->d_screen; a.sy = ctx->d_screen + width;
     a.async_leaf_num = ctx->dbg_async[0]; a.async_shade_num = ctx->dbg_async[1];
+    a.group_trace = ctx->dbg_group_trace ? 1u : 0u;
     {   // where the scene can be seen at all in these slices
         uint32_t hr[4];
         mesh_screen_rect(ctx->scene_bounds, (p.flags & RR_DISPATCH_DEBUG_NO_CULL) ? nullptr : h_cams, depth, width, height, hr);

@@ -376,6 +376,106 @@ __device__ __forceinline__ void trace_blas(const BlasDev& bl, f3 O, f3 D, float 
     if (best.hit) hit_attributes(bl.tris, O, D, best);
 }
 
+// ---- group-parallel traversal: G lanes (an aligned group of 2 or 4) walk ONE ray's tree ------------------------------
+// For launches whose length is a chain of dependent rays (DispatchRays(W,H,1): k_render_paths): once most lanes of a wave
+// have finished their path, a ray level costs as many loop trips as its longest ray has node visits, with a handful of lanes
+// taking part.  Here the rays still alive are compacted to the front of the wave and each gets G lanes.  Every lane keeps an
+// ordinary depth-first stack of its own (so the tree depth still bounds it); a lane that runs out of work takes the OLDEST
+// entry -- the root of the largest untouched subtree -- of its right-hand neighbour's stack (a ring inside the group: work
+// spreads from the lane that starts at the root), and the closest hit so far is shared for culling after every trip.  The
+// winner -- smallest t, ties to the lower primitive, exactly trace_blas's rule -- is the same triangle whatever the order.
+template <int G> __device__ __forceinline__ uint32_t grp_next(uint32_t v);     // v of the next lane of the group's ring
+template <int G> __device__ __forceinline__ uint32_t grp_prev(uint32_t v);
+template <> __device__ __forceinline__ uint32_t grp_next<4>(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x39, 0xf, 0xf, true); }   // quad_perm:[1,2,3,0]
+template <> __device__ __forceinline__ uint32_t grp_prev<4>(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x93, 0xf, 0xf, true); }   // quad_perm:[3,0,1,2]
+template <> __device__ __forceinline__ uint32_t grp_next<2>(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, true); }   // quad_perm:[1,0,3,2]
+template <> __device__ __forceinline__ uint32_t grp_prev<2>(uint32_t v) { return grp_next<2>(v); }
+template <int G> __device__ __forceinline__ float grp_min_f(float v)
+{
+    float m = fminf(v, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xb1, 0xf, 0xf, true)));              // [1,0,3,2]
+    if (G == 4) m = fminf(m, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(m), 0x4e, 0xf, 0xf, true)));        // [2,3,0,1]
+    return m;
+}
+template <int G> __device__ __forceinline__ uint32_t grp_min_u(uint32_t v)
+{
+    uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, true);
+    uint32_t m = v < o ? v : o;
+    if (G == 4) { o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x4e, 0xf, 0xf, true); m = m < o ? m : o; }
+    return m;
+}
+
+// Called by ALL 64 lanes of a wave.  alive / m_alive: the lanes that have a ray to trace (at most 64 / G of them); ww: the
+// wave's stack region as 32-bit words (at least 9 rows of 64) -- the stacks are empty between two rays, so the region also
+// carries the rays to their groups and the results back; stk: the lane's own stack column.  On return the alive lanes hold
+// what trace_blas would have given them.
+template <int G, bool STATS, class E>
+__device__ __forceinline__ void trace_blas_group(const BlasDev& bl, bool alive, unsigned long long m_alive, f3 O, f3 D, float tmin, float tmax,
+                                                 uint32_t cull, HitRec& best, E* stk, uint32_t* ww, uint32_t lane, TravCounters& cnt)
+{
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_alive >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_alive, 0u));
+    const uint32_t n_rays = (uint32_t)__popcll(m_alive);
+    if (alive) {
+        ww[0 * 64 + rank] = __float_as_uint(O.x); ww[1 * 64 + rank] = __float_as_uint(O.y); ww[2 * 64 + rank] = __float_as_uint(O.z);
+        ww[3 * 64 + rank] = __float_as_uint(D.x); ww[4 * 64 + rank] = __float_as_uint(D.y); ww[5 * 64 + rank] = __float_as_uint(D.z);
+        ww[6 * 64 + rank] = __float_as_uint(tmax); ww[7 * 64 + rank] = cull; ww[8 * 64 + rank] = __float_as_uint(tmin);
+    }
+    const uint32_t g = lane / G;
+    const bool work = g < n_rays;
+    const uint32_t gs = work ? g : 0u;
+    const f3 Og = mk3(__uint_as_float(ww[0 * 64 + gs]), __uint_as_float(ww[1 * 64 + gs]), __uint_as_float(ww[2 * 64 + gs]));
+    const f3 Dg = mk3(__uint_as_float(ww[3 * 64 + gs]), __uint_as_float(ww[4 * 64 + gs]), __uint_as_float(ww[5 * 64 + gs]));
+    const float tmaxg = __uint_as_float(ww[6 * 64 + gs]);
+    const uint32_t cullg = ww[7 * 64 + gs];
+    const float tming = __uint_as_float(ww[8 * 64 + gs]);        // (a helper lane's own tmin / tmax are those of the level its path ended at)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the rows are stack space again from here on
+
+    const BoxRay br = box_ray(Og, Dg, bl.scale, bl.grid);
+    const QNode* __restrict__ nodes = bl.nodes;
+    E* const col0 = stk - lane;                                   // entry e of lane l at col0[e * 64 + l]
+    E* top = stk;
+    E* bot = stk;                                                 // entries below bot have been taken by the neighbour
+    int node = (work && (lane % G) == 0u) ? 0 : TRAV_DONE;
+    HitRec b;
+    b.t = tmaxg; b.hit = false; b.prim = 0; b.leaf = 0; b.inst = 0; b.U = 0.0f; b.V = 0.0f; b.ad = 1.0f;
+    float tq = tmaxg;                                             // closest hit of the whole group so far
+    for (;;) {
+        const int n_in = __popcll(__ballot(node >= 0));
+        while (node >= 0) {
+            if (leaf_phase_due(n_in)) break;
+            const NodeQ q = load_node(nodes, node);
+            if (STATS) { cnt.nodes++; if (first_active_lane()) cnt.node_trips++; }
+            node = node_step(br, q, tming, tq, top, bot);
+        }
+        if (node < 0 && node != TRAV_DONE) {
+            if (STATS) { cnt.tris++; if (first_active_lane()) cnt.leaf_trips++; }
+            tri_test(bl.tris, (uint32_t)~node, Og, Dg, tming, cullg, 0u, b);
+            if (top > bot) { top -= STACK_STRIDE; node = StackCodec<E>::dec(*top); } else node = TRAV_DONE;
+        }
+        // all 64 lanes again: share the closest hit, hand work round the ring
+        tq = grp_min_f<G>(b.t);
+        const bool idle = node == TRAV_DONE;                      // (an idle lane's own stack is empty)
+        const uint32_t nb_bot = grp_next<G>((uint32_t)(bot - col0)), nb_has = grp_next<G>(top > bot ? 1u : 0u);
+        const uint32_t thief_idle = grp_prev<G>(idle ? 1u : 0u);
+        if (idle && nb_has) node = StackCodec<E>::dec(col0[nb_bot]);
+        if (top > bot && thief_idle) bot += STACK_STRIDE;
+        if (__ballot(node != TRAV_DONE) == 0ull) break;
+    }
+    // the group's closest hit: smallest t, ties to the lower primitive
+    const float tw = grp_min_f<G>(b.hit ? b.t : 3.0e38f);
+    const bool cand = b.hit && b.t == tw;
+    const uint32_t prim = cand ? bl.tris[b.leaf].prim : 0xffffffffu;
+    const uint32_t pw = grp_min_u<G>(prim);
+    const uint32_t lw = ~grp_min_u<G>((cand && prim == pw) ? ~b.leaf : 0xffffffffu);
+    if (work && (lane % G) == 0u) { ww[0 * 64 + g] = __float_as_uint(tw); ww[1 * 64 + g] = tw < 3.0e38f ? lw : 0xffffffffu; }
+    best.t = tmax; best.hit = false; best.prim = 0; best.leaf = 0; best.inst = 0; best.U = 0.0f; best.V = 0.0f; best.ad = 1.0f;
+    if (alive) {
+        const uint32_t l = ww[1 * 64 + rank];
+        if (l != 0xffffffffu) { best.t = __uint_as_float(ww[0 * 64 + rank]); best.leaf = l; best.hit = true; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (best.hit) hit_attributes(bl.tris, O, D, best);
+}
+
 __device__ __forceinline__ f3 xform_point(const float* m, f3 p)
 {
     return mk3(((m[0] * p.x + m[1] * p.y) + m[2] * p.z) + m[3],

@@ -101,62 +101,108 @@ __global__ __launch_bounds__(256, WPS ? WPS : TLAS ? RR_TLAS_WAVES_PER_SIMD(STAC
 // on their SIMD anyway).
 struct PathLeaf { float w; f3 e; };
 
+// Called by all 64 lanes of all four waves of the workgroup (valid: the lane has a pixel; it contains workgroup barriers).
+// ww: the wave's stack region as 32-bit words; xch: wave 1's.  Levels with few rays left are traced by groups of lanes
+// (trace_blas_group): 2 lanes per ray from 32 rays down, 4 from 16.
 template <bool STATS, bool TLAS, class E>
-__device__ __forceinline__ PathLeaf render_path(const SceneDev& sc, const DispatchDev& a, const CamDev& cb, uint32_t x, uint32_t y,
-                                                uint32_t path, E* stk, LaneStats& st, uint32_t* diag_lv = nullptr)
+__device__ __forceinline__ PathLeaf render_path(const SceneDev& sc, const DispatchDev& a, const CamDev& cb, uint32_t x, uint32_t y, bool valid,
+                                                uint32_t path, E* stk, uint32_t* ww, uint32_t* xch, uint32_t lane, LaneStats& st, uint32_t* diag_lv = nullptr)
 {
     PathLeaf leaf; leaf.w = 0.0f; leaf.e = mk3(0.0f, 0.0f, 0.0f);
     f3 O = mk3(cb.cam[0], cb.cam[1], cb.cam[2]);
-    f3 D = camera_ray_dir(cb.M, a.sx[x], a.sy[y]);
+    f3 D = valid ? camera_ray_dir(cb.M, a.sx[x], a.sy[y]) : mk3(0.0f, 0.0f, 1.0f);
     float w = 1.0f;
     uint32_t count = 0;
-    bool outside = true;
+    bool outside = true, alive = valid;
     float tmin = a.tmin_p, tmax = a.tmax_p;
-    for (;;) {
+    for (uint32_t level = 0;; ++level) {
+        const unsigned long long m_alive = __ballot(alive);
+        if (level >= 2u && m_alive == 0ull) break;          // (levels 0 and 1 hold workgroup barriers: every wave goes through them)
+        const int n_alive = __popcll(m_alive);
         // the lane that accounts for this ray (and owns its leaf, should it be one): rays at count 0 are shared by the four
         // lanes of the pixel, rays at count 1 by the two with the same first turn
-        const bool owner = count == 0u ? path == 0u : count == 1u ? (path & 1u) == 0u : true;
-        if (diag_lv) {      // diagnostic builds: lanes alive at this level, time at which it starts
-            const uint32_t n_alive = (uint32_t)__popcll(__ballot(1));
-            if (first_active_lane()) diag_lv[count < 15u ? count : 15u] = n_alive | ((uint32_t)__builtin_amdgcn_s_memrealtime() << 8);
+        const bool owner = level == 0u ? path == 0u : level == 1u ? (path & 1u) == 0u : true;
+        if (diag_lv && alive) {      // diagnostic builds: lanes alive at this level, time at which it starts
+            if (first_active_lane()) diag_lv[level < 15u ? level : 15u] = (uint32_t)n_alive | ((uint32_t)__builtin_amdgcn_s_memrealtime() << 8);
         }
         HitRec h;
+        h.t = tmax; h.hit = false; h.prim = 0; h.leaf = 0; h.inst = 0; h.U = 0.0f; h.V = 0.0f; h.ad = 1.0f;
         TravCounters cnt; cnt.nodes = 0; cnt.tris = 0;
-        trace_scene<STATS, TLAS, E, GlobalNodes>(sc, O, D, tmin, tmax, outside ? CULL_BACK : CULL_FRONT, h, stk, cnt);
-        if (owner) { ++st.rays; if (STATS) { st.cnt.nodes += cnt.nodes; st.cnt.tris += cnt.tris; } }
-        if (STATS) { st.cnt.node_trips += cnt.node_trips; st.cnt.leaf_trips += cnt.leaf_trips; if (first_active_lane()) ++st.passes; }
-        if (!h.hit) {                                             // Miss
-            if (owner) { if (STATS) ++st.miss; leaf.w = w; leaf.e = env_lookup(sc, D); }
-            break;
+        const uint32_t cullf = outside ? CULL_BACK : CULL_FRONT;
+        if (level < 2u) {
+            // A shared ray is traced ONCE: by wave 0 at level 0 (the primary ray of the block's 64 pixels), by waves 0 and 2 at
+            // level 1 (the refracted and the reflected child); the closest hit -- t, leaf, instance -- goes to the other waves of
+            // the workgroup through LDS (`xch`: rows of wave 1's stack region, which does not trace before level 2) and each
+            // shades it for its own path: the hit attributes and the shading are the same arithmetic on the same operands.
+            uint32_t* const row = xch + (level == 0u ? 0u : 3u + 3u * (path >> 1)) * 64u + lane;
+            if (owner) {
+                if (alive) trace_scene<STATS, TLAS, E, GlobalNodes>(sc, O, D, tmin, tmax, cullf, h, stk, cnt);
+                row[0] = __float_as_uint(h.t); row[64] = h.hit ? h.leaf : 0xffffffffu; row[128] = h.inst;
+            }
+            __syncthreads();
+            if (!owner && alive) {
+                const uint32_t l = row[64];
+                if (l != 0xffffffffu) {
+                    h.t = __uint_as_float(row[0]); h.leaf = l; h.inst = row[128]; h.hit = true;
+                    if (!TLAS) hit_attributes(sc.blas0.tris, O, D, h);
+                    else {
+                        const InstDev& in = sc.insts[h.inst];
+                        f3 Oh = O, Dh = D;
+                        if (!in.identity) { Oh = xform_point(in.inv, O); Dh = xform_dir(in.inv, D); }
+                        hit_attributes(sc.pool_tris, Oh, Dh, h);
+                    }
+                }
+            }
+            if (level == 1u) __syncthreads();               // wave 1's stack region is a stack again from here on
+        } else if (!TLAS && a.group_trace != 0u && n_alive <= 16) {
+            trace_blas_group<4, STATS, E>(sc.blas0, alive, m_alive, O, D, tmin, tmax, cullf, h, stk, ww, lane, cnt);
+            if (STATS) { st.cnt.nodes += cnt.nodes; st.cnt.tris += cnt.tris; cnt.nodes = 0; cnt.tris = 0; }
+        } else if (!TLAS && a.group_trace != 0u && n_alive <= 32) {
+            trace_blas_group<2, STATS, E>(sc.blas0, alive, m_alive, O, D, tmin, tmax, cullf, h, stk, ww, lane, cnt);
+            if (STATS) { st.cnt.nodes += cnt.nodes; st.cnt.tris += cnt.tris; cnt.nodes = 0; cnt.tris = 0; }
+        } else if (alive) {
+            trace_scene<STATS, TLAS, E, GlobalNodes>(sc, O, D, tmin, tmax, cullf, h, stk, cnt);
         }
-        if (STATS && owner) ++st.hits;
-        if ((int)count >= a.max_refract) { if (STATS && owner) ++st.term; break; }      // hlsl:82, payload.color stays 0
-        const f3 N = shading_normal<TLAS>(sc, h);
-        const f3 X = mk3(fmaf(h.t, D.x, O.x), fmaf(h.t, D.y, O.y), fmaf(h.t, D.z, O.z));
-        const f3 Nf = outside ? N : neg3(N);
-        const float R0 = (0.2f / 2.2f) * (0.2f / 2.2f);
-        const float b = 1.0f - dot3(D, Nf);
-        const float b2 = b * b, b4 = b2 * b2;
-        const float R = (R0 * (1.0f - R0)) * (b4 * b);
-        const float eta = outside ? a.inv_ior : a.ior;
-        f3 d1;
-        const bool refr = refract_ray(d1, D, Nf, eta);
-        if (STATS && owner && !refr) ++st.tir;
-        const bool refl = (int)count < a.max_reflect;
-        // which child this lane follows: the reflected one where its path says so (count 0: bit 1, count 1: bit 0), else the
-        // refracted one; k_render_fused follows the refracted child and parks the reflected one, or, without a refracted
-        // child, follows the reflected one directly -- that one is then the node's only subtree, and it belongs to the
-        // "reflect" lanes here as well (the "refract" lanes have no leaf below this node)
-        const bool turn = count == 0u ? (path & 2u) != 0u : count == 1u ? (path & 1u) != 0u : false;
-        const uint32_t c1 = count + 1u;
-        tmin = a.tmin_s; tmax = a.tmax_s;
-        O = X;
-        if (!turn) {
-            if (!refr) break;
-            D = d1; w = w * (1.0f - R); count = c1; outside = !outside;
-        } else {
-            if (!refl) break;
-            D = normalize3(reflect_ray(D, Nf)); w = w * R; count = c1;
+        if (STATS) { st.cnt.node_trips += cnt.node_trips; st.cnt.leaf_trips += cnt.leaf_trips; }
+        if (alive) {
+            if (owner) { ++st.rays; if (STATS) { st.cnt.nodes += cnt.nodes; st.cnt.tris += cnt.tris; } }
+            if (STATS && first_active_lane()) ++st.passes;
+            if (!h.hit) {                                             // Miss
+                if (owner) { if (STATS) ++st.miss; leaf.w = w; leaf.e = env_lookup(sc, D); }
+                alive = false;
+            } else {
+                if (STATS && owner) ++st.hits;
+                if ((int)count >= a.max_refract) { if (STATS && owner) ++st.term; alive = false; }      // hlsl:82, payload.color stays 0
+                else {
+                    const f3 N = shading_normal<TLAS>(sc, h);
+                    const f3 X = mk3(fmaf(h.t, D.x, O.x), fmaf(h.t, D.y, O.y), fmaf(h.t, D.z, O.z));
+                    const f3 Nf = outside ? N : neg3(N);
+                    const float R0 = (0.2f / 2.2f) * (0.2f / 2.2f);
+                    const float b = 1.0f - dot3(D, Nf);
+                    const float b2 = b * b, b4 = b2 * b2;
+                    const float R = (R0 * (1.0f - R0)) * (b4 * b);
+                    const float eta = outside ? a.inv_ior : a.ior;
+                    f3 d1;
+                    const bool refr = refract_ray(d1, D, Nf, eta);
+                    if (STATS && owner && !refr) ++st.tir;
+                    const bool refl = (int)count < a.max_reflect;
+                    // which child this lane follows: the reflected one where its path says so (count 0: bit 1, count 1: bit 0), else the
+                    // refracted one; k_render_fused follows the refracted child and parks the reflected one, or, without a refracted
+                    // child, follows the reflected one directly -- that one is then the node's only subtree, and it belongs to the
+                    // "reflect" lanes here as well (the "refract" lanes have no leaf below this node)
+                    const bool turn = count == 0u ? (path & 2u) != 0u : count == 1u ? (path & 1u) != 0u : false;
+                    const uint32_t c1 = count + 1u;
+                    tmin = a.tmin_s; tmax = a.tmax_s;
+                    O = X;
+                    if (!turn) {
+                        if (!refr) alive = false;
+                        else { D = d1; w = w * (1.0f - R); count = c1; outside = !outside; }
+                    } else {
+                        if (!refl) alive = false;
+                        else { D = normalize3(reflect_ray(D, Nf)); w = w * R; count = c1; }
+                    }
+                }
+            }
         }
     }
     return leaf;
@@ -173,19 +219,21 @@ __global__ __launch_bounds__(256, TLAS ? 5 : 8) void k_render_paths(SceneDev sc,
     LaneStats st;
     stats_clock_begin<STATS>(st);
     if (blockIdx.x < n_pp_blocks) {
-        uint32_t* stk = lds + wave * (STACK * 64) + lane;
+        // (Measured and rejected, round 3: starting last launch's slowest blocks first -- as cost classes, whose empty workgroups cost
+        // 30 ns each, and as the previous launch's completion order walked backwards: 250 us per frame against 245 on monkey.obj,
+        // 450 against 397 on sphere.obj.  A chain of dependent rays runs at 220 us under the full chip's load and at 150 us on an
+        // idle one, so a slow block gains nothing from starting while everything else does, and raster order keeps neighbours in L2.)
         const uint32_t frame = blockIdx.x % a.n_frames, b = blockIdx.x / a.n_frames;
+        uint32_t* stk = lds + wave * (STACK * 64) + lane;
         // wave p follows path p of the block's 64 pixels: the lanes of a wave then trace rays of one kind (all refracted twice,
         // all reflected then refracted, ...), which stay closer together than the four paths of one pixel do
         const uint32_t path = wave;
         const uint32_t x = a.hx0 + (b % rect_bw) * 8u + compact1by1(lane), y = a.hy0 + (b / rect_bw) * 8u + compact1by1(lane >> 1);
         const bool valid = x < a.W && y < a.H;
-        PathLeaf lf; lf.w = 0.0f; lf.e = mk3(0.0f, 0.0f, 0.0f);
         st.blocks = 1u;                 // (a quarter of an 8x8 block: the per-wave cost of the issue model does not apply to this kernel)
-        if (valid) {
-            if (path == 0u) st.pixels = 1;
-            lf = render_path<STATS, TLAS, uint32_t>(sc, a, a.cams[frame], x, y, path, stk, st, DIAG ? diag_lv[wave] : nullptr);
-        }
+        if (valid && path == 0u) st.pixels = 1;
+        const PathLeaf lf = render_path<STATS, TLAS, uint32_t>(sc, a, a.cams[frame], x, y, valid, path, stk, lds + wave * (STACK * 64), lds + 1 * (STACK * 64), lane, st,
+                                                               DIAG ? diag_lv[wave] : nullptr);
         // the pixel's colour: its leaves in the recursion's order, handed over through the (now idle) stack space
         float* const mine = reinterpret_cast<float*>(lds + wave * (STACK * 64)) + lane;
         mine[0] = lf.w; mine[64] = lf.e.x; mine[128] = lf.e.y; mine[192] = lf.e.z;

@@ -225,8 +225,8 @@ __global__ __launch_bounds__(256, WPS) void k_stream_rays(SceneDev sc, DispatchD
             const int n_shade = n_fin + (more ? n_idle : 0);
             if (n_node + n_tri + n_ent + n_exit + n_shade == 0) break;
             const int n_alive = 64 - (more ? 0 : n_idle);
-            serve = (n_alive * (int)a.async_leaf_num + 7) / 8;
-            need_lanes = (n_alive * (int)a.async_shade_num + 7) / 8;
+            serve = (n_alive * (int)a.async_leaf_num + 15) / 16;
+            need_lanes = (n_alive * (int)a.async_shade_num + 15) / 16;
             if (n_node < serve * 2 && n_tri < serve && n_ent < serve && n_exit < serve && (n_shade < need_lanes || n_shade == 0)) {
                 pick = 0; int mx = n_node;
                 if (n_tri > mx) { mx = n_tri; pick = 1; }

@@ -384,8 +384,17 @@ def test_lds_and_path_parallel_kernels_render_the_same_frames(tmp_path):
         assert p.returncode == 0, p.stderr[-2000:]
         res[tag] = (np.load(tmp_path / (tag + ".npy")), p.stdout.split())
     for tag in res:
-        assert np.array_equal(res["fused"][0], res[tag][0]), tag
-        assert res["fused"][1] == res[tag][1], tag
+        if not np.array_equal(res["fused"][0], res[tag][0]):
+            bad = np.argwhere(res["fused"][0] != res[tag][0])
+            raise AssertionError("%s: %d values differ, first at %s: %r / %r" % (tag, len(bad), bad[0], res["fused"][0][tuple(bad[0])], res[tag][0][tuple(bad[0])]))
+        a, b = list(res["fused"][1]), list(res[tag][1])
+        if tag.startswith("paths"):
+            # k_render_paths traces the sparse late ray levels with 2 or 4 lanes per ray (trace_blas_group): the same closest hits
+            # in a different visiting order, so node_visits / tri_tests (entries 5, 6 of each group of 8) are its own; the ray,
+            # hit, miss, terminal-hit, TIR and pixel counts are the recursion's and must be equal
+            keep = [i for i in range(len(a)) if not ((i % 25) < 24 and (i % 25) % 8 in (5, 6))]      # per mesh: 3 x 8 counters + the sharded ray count
+            a, b = [a[i] for i in keep], [b[i] for i in keep]
+        assert a == b, tag
 
 
 def test_ploc_builder_makes_progress_on_equal_and_overflowing_areas(gpu):

@@ -15,7 +15,8 @@ r = rr.Renderer(0)
 m = rr.Mesh(); assert m.load(asset(name))
 r.load_scene(m.verts, m.indices, procedural_env(2048, 1024, seed=0))
 r.set_camera(rr.camera_orbit(0.01))
-for _ in range(3):
+for k in range(4):
+    r.set_camera(rr.camera_orbit(0.01 * (k + 1)))
     r.dispatch_rays(1920, 1080, rr.default_params(max_refract=refr, max_reflect=refl))
     r.wait()
 d = np.fromfile("/tmp/diag_paths.bin", dtype=np.uint64)
