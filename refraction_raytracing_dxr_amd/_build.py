@@ -12,11 +12,6 @@ LIB = os.path.join(PKG, "librrdxr.so")
 DEMO = os.path.join(PKG, "rrdemo")
 
 DEVICE_SOURCES = ["rr_bvh_build.hip", "rr_render.hip", "rr_render_stream.hip"]
-# RR_EXPERIMENTAL=1: also build the render-kernel experiments (rr_render_exp.hip: lane-asynchronous, queue-per-bounce and
-# pixel-refill renderers, selected at run time with RR_DEBUG_KERNEL); the product library does not contain them
-EXPERIMENTAL = os.environ.get("RR_EXPERIMENTAL") == "1"
-if EXPERIMENTAL:
-    DEVICE_SOURCES.append("rr_render_exp.hip")
 HOST_SOURCES = ["rr_capi.cpp", "host/rr_host_camera.cpp", "host/rr_host_mesh.cpp", "host/rr_host_image.cpp",
                 "host/Mesh.cpp", "host/RefractionDemo.cpp"]
 HEADERS = ["rr_types.h", "rr_device.h", "rr_launch.h", "rr_render_common.h", "host/Mesh.hpp", "host/RefractionDemo.hpp",
@@ -24,8 +19,7 @@ HEADERS = ["rr_types.h", "rr_device.h", "rr_launch.h", "rr_render_common.h", "ho
 
 # -ffp-contract=off: the arithmetic contract -- FMAs only where fmaf is written
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
-DEVICE_FLAGS = (["--offload-arch=gfx950", "-fno-gpu-rdc"] + (["-DRR_EXPERIMENTAL"] if EXPERIMENTAL else []) +
-                os.environ.get("RR_EXTRA_DEFINES", "").split())
+DEVICE_FLAGS = ["--offload-arch=gfx950", "-fno-gpu-rdc"] + os.environ.get("RR_EXTRA_DEFINES", "").split()
 
 
 def _hipcc():

@@ -129,36 +129,52 @@ int pumpSharded(int n_frames, int frames_per_gather, rr_stats* stats)
     const uint64_t frame_stride = (uint64_t)max_tiles * 32 * 32 * 4;              // one rank's tiles of one frame, RGBA8
     const uint64_t batch_bytes = frame_stride * (uint64_t)frames_per_gather;      // what every rank contributes per gather
     const uint64_t raster = (uint64_t)W * H * 4;
-    void *d_send = nullptr, *d_recv = nullptr, *d_frames = nullptr;
-    if ((rc = rr_device_alloc(g_ctx, batch_bytes, &d_send)) != RR_OK) return fail(rc, "rr_device_alloc");
-    if (g_rank == 0) {
-        rc = rr_device_alloc(g_ctx, batch_bytes * (uint64_t)g_world, &d_recv);
-        if (rc == RR_OK) rc = rr_device_alloc(g_ctx, raster * (uint64_t)frames_per_gather, &d_frames);
-        if (rc != RR_OK) { rr_device_free(g_ctx, d_send); rr_device_free(g_ctx, d_recv); return fail(rc, "rr_device_alloc"); }
+    // Two buffer sets and two render lanes: batch b is rendered on lane b % 2 into set b % 2 while the gather of batch b - 1
+    // (queued on the context's stream behind that lane's join) and its de-interleave run -- the gather travels under the next
+    // render instead of after it.  Set b % 2 is free again when batch b + 2 starts: the context's stream, on which gather and
+    // de-interleave of batch b were queued, is what lane b % 2 forks from.
+    void *d_send[2] = { nullptr, nullptr }, *d_recv[2] = { nullptr, nullptr }, *d_frames = nullptr;
+    auto release = [&] { for (int k = 0; k < 2; ++k) { rr_device_free(g_ctx, d_send[k]); rr_device_free(g_ctx, d_recv[k]); } rr_device_free(g_ctx, d_frames); };
+    for (int k = 0; k < 2 && rc == RR_OK; ++k) {
+        rc = rr_device_alloc(g_ctx, batch_bytes, &d_send[k]);
+        if (rc == RR_OK && g_rank == 0) rc = rr_device_alloc(g_ctx, batch_bytes * (uint64_t)g_world, &d_recv[k]);
     }
+    if (rc == RR_OK && g_rank == 0) rc = rr_device_alloc(g_ctx, raster * (uint64_t)frames_per_gather, &d_frames);
+    if (rc != RR_OK) { release(); return fail(rc, "rr_device_alloc"); }
     rr_dispatch_params p = g_opt.dispatch;
-    int last_n = 0;
-    for (int k = 0; k < n_frames && rc == RR_OK; k += frames_per_gather) {
+    int last_n = 0, pending_n = 0, pending_set = -1;
+    auto gather_pending = [&]() -> int {            // join the lane of the batch launched before, gather it, de-interleave on rank 0
+        if (pending_set < 0) return RR_OK;
+        int r = rr_lane_join(g_ctx, (uint32_t)pending_set);
+        if (r != RR_OK) return fail(r, "rr_lane_join");
+        r = rr_gather_frames(g_ctx, g_comm, g_rank, g_world, d_send[pending_set], d_recv[pending_set], batch_bytes, 0);
+        if (r != RR_OK) return fail(r, "rr_gather_frames");
+        if (g_rank == 0) {
+            r = rr_assemble_frames(g_ctx, d_recv[pending_set], (uint32_t)g_world, batch_bytes, frame_stride, (uint32_t)pending_n, W, H, d_frames, raster);
+            if (r != RR_OK) return fail(r, "rr_assemble_frames");
+        }
+        last_n = pending_n; pending_set = -1;
+        return RR_OK;
+    };
+    int b = 0;
+    for (int k = 0; k < n_frames && rc == RR_OK; k += frames_per_gather, ++b) {
         const int n = n_frames - k < frames_per_gather ? n_frames - k : frames_per_gather;
         if (k > 0) p.flags |= RR_DISPATCH_KEEP_COUNTERS;
-        rc = rr_render_orbit_sharded(g_ctx, W, H, &p, &g_angle, g_opt.angle_step, (uint32_t)n, (uint32_t)n, g_opt.fov_y, g_opt.aspect,
-                                     g_opt.zn, g_opt.zf, d_send, frame_stride);
-        if (rc != RR_OK) { fail(rc, "rr_render_orbit_sharded"); break; }
-        rc = rr_gather_frames(g_ctx, g_comm, g_rank, g_world, d_send, d_recv, batch_bytes, 0);
-        if (rc != RR_OK) { fail(rc, "rr_gather_frames"); break; }
-        if (g_rank == 0) {
-            rc = rr_assemble_frames(g_ctx, d_recv, (uint32_t)g_world, batch_bytes, frame_stride, (uint32_t)n, W, H, d_frames, raster);
-            if (rc != RR_OK) { fail(rc, "rr_assemble_frames"); break; }
-        }
-        last_n = n;
+        rc = rr_render_orbit_sharded_lane(g_ctx, W, H, &p, &g_angle, g_opt.angle_step, (uint32_t)n, (uint32_t)n, g_opt.fov_y, g_opt.aspect,
+                                          g_opt.zn, g_opt.zf, d_send[b & 1], frame_stride, (uint32_t)(b & 1));
+        if (rc != RR_OK) { fail(rc, "rr_render_orbit_sharded_lane"); break; }
+        if ((rc = gather_pending()) != RR_OK) break;
+        pending_set = b & 1; pending_n = n;
     }
+    if (rc == RR_OK) rc = gather_pending();
     if (rc == RR_OK && g_rank == 0 && last_n > 0) {
         rc = rr_device_read(g_ctx, (const uint8_t*)d_frames + (uint64_t)(last_n - 1) * raster, g_back.data(), raster);
         if (rc != RR_OK) fail(rc, "rr_device_read");
     }
     if (rc == RR_OK) { rc = rr_wait(g_ctx); if (rc != RR_OK) fail(rc, "rr_wait"); }
     if (rc == RR_OK && stats && (rc = rr_get_stats(g_ctx, stats)) != RR_OK) fail(rc, "rr_get_stats");
-    rr_device_free(g_ctx, d_send); rr_device_free(g_ctx, d_recv); rr_device_free(g_ctx, d_frames);
+    if (rc != RR_OK) (void)rr_wait(g_ctx);
+    release();
     return rc;
 }
 

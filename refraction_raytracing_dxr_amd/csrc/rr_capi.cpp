@@ -30,7 +30,10 @@ static_assert(sizeof(rr_ray) == sizeof(rr_ray_dev) && sizeof(rr_hit) == sizeof(r
 // Optional roctx ranges around the coarse steps (build, dispatch, assemble) so that `rocprofv3 --marker-trace`
 // shows them next to the kernels.  The marker library is looked up at run time; without it the calls are no-ops.
 #include <dlfcn.h>
-#include <rccl/rccl.h>      // types only (ncclUniqueId, ncclUint8): the library is looked up with dlopen, nothing links against it
+// RCCL is looked up with dlopen (nothing links against it, and building needs no RCCL header): the two things of its ABI that
+// cross this file are declared here -- the 128-byte unique id, passed by value to ncclCommInitRank, and ncclUint8 of ncclDataType_t
+struct rr_nccl_unique_id { char internal[128]; };
+enum { RR_NCCL_UINT8 = 1 };
 namespace {
 struct Roctx {
     int (*push)(const char*) = nullptr;
@@ -160,14 +163,14 @@ struct rr_context {
     uint32_t* d_tickets = nullptr;   // k_render_lds ticket words: one block per stream a launch can be on (lanes, then the context's stream)
 
     // diagnostics switches, read once at rr_create (never needed for correct results)
-    int  dbg_kernel = 0;             // RR_DEBUG_KERNEL: 0 default, 1 "fused" (never the LDS kernel), 2 "async", 3 "wavefront", 4 "lds" (at every depth), 10 "stream"
+    int  dbg_kernel = 0;             // RR_DEBUG_KERNEL: 0 default (measured choice), 1 "fused", 4 "lds", 5 "paths", 10 "stream": that kernel wherever it can render the launch
     int  dbg_stack = 0;              // RR_DEBUG_STACK
     int  dbg_ticket_blocks = 0;      // RR_DEBUG_TICKET: 1 = k_render_lds treats the whole frame as the mesh rectangle, 2 = no rectangle
     bool dbg_group_trace = true;     // RR_DEBUG_GROUP_TRACE=0: k_render_paths never shares a ray between lanes
     bool dbg_async_set = false;
-    uint32_t dbg_async[2] = { 2, 2 };    // RR_DEBUG_ASYNC="leaf,shade": thresholds of k_render_scene_async in eighths (rr_types.h)
+    uint32_t dbg_async[2] = { 2, 2 };    // RR_DEBUG_ASYNC="step,shade": issue thresholds of k_stream_rays in sixteenths of the live lanes
     bool dbg_tile_order = true;      // RR_DEBUG_TILE_ORDER=0: tiles in image order (DispatchDev::rt_*)
-    int  dbg_stream_waves = 6;       // RR_DEBUG_STREAM_WAVES: waves per SIMD k_render_scene_stream is built for (5..7)
+    int  dbg_stream_waves = 6;       // RR_DEBUG_STREAM_WAVES: waves per SIMD k_stream_rays is built for (5..8)
     bool dbg_tlas32 = false;         // RR_DEBUG_TLAS32: two-level scenes keep 32-bit stack entries and register-parked rays
     int  dbg_shape = 0;              // RR_DEBUG_SHAPE: first k_render_lds workgroup shape to consider (rr_launch.h)
     std::string dbg_diag;            // RR_DEBUG_DIAG: file that receives per-wave diagnostics of Depth-1 dispatches
@@ -176,10 +179,6 @@ struct rr_context {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> kev;     // pairs
     uint32_t kev_used = 0;
-
-    // experimental queue-per-bounce renderer (RR_DEBUG_KERNEL=wavefront)
-    WfBuffers wf = { { nullptr, nullptr }, nullptr, nullptr, nullptr, 0 };
-    size_t    wf_pixels = 0;
 
     // k_stream_* (rr_render_stream.hip): ray queues, leaf slots and pixel marks of one pass; grown on demand, never shrunk
     StreamDev strm = { { nullptr, nullptr }, { nullptr, nullptr }, nullptr, nullptr, nullptr, nullptr, 0, 0 };
@@ -386,7 +385,7 @@ int rr_create(int device_ordinal, rr_context** out)
     (void)hipMemsetAsync(ctx->d_cnt, 0, sizeof(CounterBlock), ctx->stream);
     (void)hipMemsetAsync(ctx->d_tickets, 0, (rr_context::MAX_LANES + 1) * LDS_TICKET_WORDS * sizeof(uint32_t), ctx->stream);   // the kernel leaves them zero
     if (const char* e = getenv("RR_DEBUG_KERNEL"))
-        ctx->dbg_kernel = !strcmp(e, "fused") ? 1 : !strcmp(e, "async") ? 2 : !strcmp(e, "wavefront") ? 3 : !strcmp(e, "lds") ? 4 : !strcmp(e, "paths") ? 5 : !strcmp(e, "refill") ? 6 : !strcmp(e, "scene-async") ? 8 : !strcmp(e, "scene-stream") ? 9 : !strcmp(e, "stream") ? 10 : 0;
+        ctx->dbg_kernel = !strcmp(e, "fused") ? 1 : !strcmp(e, "lds") ? 4 : !strcmp(e, "paths") ? 5 : !strcmp(e, "stream") ? 10 : 0;
     if (const char* e = getenv("RR_DEBUG_STACK")) ctx->dbg_stack = atoi(e);
     if (const char* e = getenv("RR_DEBUG_TICKET")) ctx->dbg_ticket_blocks = atoi(e);
     if (const char* e = getenv("RR_DEBUG_SHAPE")) ctx->dbg_shape = atoi(e);
@@ -415,7 +414,6 @@ int rr_destroy(rr_context* ctx)
     }
     for (MeshRes& m : ctx->meshes) { dfree(m.d_verts); dfree(m.d_idx); dfree(m.nodes); dfree(m.qnodes); dfree(m.tris); dfree(m.nrms); }
     dfree(ctx->d_env); dfree(ctx->d_insts); dfree(ctx->d_pool_nodes); dfree(ctx->d_pool_qnodes); dfree(ctx->d_pool_tris); dfree(ctx->d_pool_nrms); dfree(ctx->d_rgba8); dfree(ctx->d_f32);
-    dfree(ctx->wf.q[0]); dfree(ctx->wf.q[1]); dfree(ctx->wf.slots); dfree(ctx->wf.hit_list); dfree(ctx->wf.counts);
     dfree(ctx->strm.q[0]); dfree(ctx->strm.q[1]); dfree(ctx->strm.fill[0]); dfree(ctx->strm.fill[1]); dfree(ctx->strm.heads); dfree(ctx->strm.slots); dfree(ctx->strm.pending);
     for (hipEvent_t e : ctx->ch_ev) if (e) (void)hipEventDestroy(e);
     dfree(ctx->d_assembled); dfree(ctx->d_cnt); dfree(ctx->d_tickets); dfree(ctx->d_screen);
@@ -895,7 +893,7 @@ int render_stream(rr_context* ctx, const SceneDev& sc, const DispatchDev& a, uin
         DispatchDev b = a;
         // lanes (in sixteenths of the wave's live lanes) a step / a shading pass needs to be issued: measured on the
         // 1 024-instance scene (tools/exp_stream_sweep.sh; RR_DEBUG_ASYNC overrides)
-        if (!ctx->dbg_async_set) { b.async_leaf_num = 2u; b.async_shade_num = 6u; }
+        if (!ctx->dbg_async_set) { b.async_leaf_num = 2u; b.async_shade_num = 8u; }
         b.cams = a.cams + f0;
         b.n_frames = fc;
         b.n_blocks = a.blocks_per_frame * fc;
@@ -1009,29 +1007,6 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
             RR_HIP(hipMemsetAsync(reinterpret_cast<uint8_t*>(a.out_rgba8 + f * stride) + (size_t)local * TILE * TILE * (rgb8 ? 3 : 4), 0,
                                   (size_t)(max_local - local) * TILE * TILE * (rgb8 ? 3 : 4), ctx->stream));
     int stack_sel = need <= 19 ? 19 : need <= 22 ? 22 : need <= 26 ? 26 : need <= 31 ? 31 : need <= 39 ? 39 : 64;     // rr_render.hip: sizes that fill the LDS with 6 / 5 / 4 / 2 workgroups
-#ifdef RR_EXPERIMENTAL
-    const bool wavefront = ctx->dbg_kernel == 3 && ctx->single_identity && !compact && !want_f32 && !stats && p.max_reflect <= 2 && p.max_refract < 62;
-#else
-    const bool wavefront = false;
-#endif
-    if (wavefront) {        // experiment: queue-per-bounce kernels; buffers sized for this dispatch
-        const size_t px = (size_t)width * height * depth;
-        if (px > ctx->wf_pixels) {
-            RR_HIP(hipStreamSynchronize(ctx->stream));
-            dfree(ctx->wf.q[0]); dfree(ctx->wf.q[1]); dfree(ctx->wf.slots); dfree(ctx->wf.hit_list); dfree(ctx->wf.counts);
-            ctx->wf_pixels = 0;
-            // (experiment only.  Generation 1 holds the refracted AND the reflected child of every covered pixel, generation 2
-            // up to four per pixel: a close-up that covers more than about half the frame overflows this queue, which the
-            // kernels report through the error flag)
-            ctx->wf.cap = (uint32_t)std::min<size_t>(px + 65536, 0x7fffffffu);
-            RR_HIP(hipMalloc(&ctx->wf.q[0], (size_t)ctx->wf.cap * 48));
-            RR_HIP(hipMalloc(&ctx->wf.q[1], (size_t)ctx->wf.cap * 48));
-            RR_HIP(hipMalloc(&ctx->wf.slots, px * 64));
-            RR_HIP(hipMalloc(&ctx->wf.hit_list, px * 4));
-            RR_HIP(hipMalloc(&ctx->wf.counts, 64 * 4));
-            ctx->wf_pixels = px;
-        }
-    }
     if (ctx->dbg_stack >= (int)need) stack_sel = ctx->dbg_stack;   // experiments only; never below the tree depth (the kernels do not check)
     // the reference's scene with a node array small enough for LDS (its own meshes up to shell.obj): persistent workgroups,
     // nodes read from LDS
@@ -1060,17 +1035,9 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     }
     const bool refill_stack16 = ctx->single_identity ? (m0 && m0->n_tris < 32768u && need > 19)
                                                      : (pool_nodes < 32768u && ctx->n_pool_tris + ctx->n_insts < 32768u);
-    // (experiment, RR_DEBUG_KERNEL=scene-async: the lane-asynchronous kernel for scenes with a TLAS, see rr_render_exp.hip)
-    const bool scene_stream = ctx->dbg_kernel == 9 && !ctx->single_identity && p.max_reflect <= 2 && need <= 30 && refill_stack16 && !compact && !a.diag &&
-                              ctx->dbg_stack == 0;
-    const bool scene_async = ctx->dbg_kernel == 8 && !ctx->single_identity && p.max_reflect <= 2 && need <= 39 && !a.diag && ctx->dbg_stack == 0;
-    // (experiment, RR_DEBUG_KERNEL=refill: on the 1 024-monkey grid it raises the share of live lanes per shading pass from
-    // 54 % to 80 % and the frame time from 8.9 to 10.8 ms -- a pass lasts as long as its longest ray either way, and with
-    // every lane alive that one is longer)
-    const bool refill_kernel = ctx->dbg_kernel == 6 && p.max_reflect <= 2 && need <= 39 && !a.diag && ctx->dbg_stack == 0;
     // ---- the candidates
     const bool stream_ok = !ctx->single_identity && p.max_reflect <= 2 && p.max_refract <= (int)STREAM_MAX_GEN - 2 && refill_stack16 && need <= 39 &&
-                           !a.diag && ctx->dbg_stack == 0 && !scene_stream && !scene_async && !refill_kernel && !ctx->dbg_tlas32;
+                           !a.diag && ctx->dbg_stack == 0 && !ctx->dbg_tlas32;
     const bool paths_ok = !compact && ctx->tile_world == 1 && p.max_reflect <= 2 && need <= 39 && ctx->dbg_stack == 0 && have_rect && depth <= 2;
     auto launch_fused = [&](bool st) -> int {
         // deep trees of small meshes: 16-bit stack entries keep eight waves per SIMD (LDS would otherwise allow 6/5/4)
@@ -1175,15 +1142,6 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         }
         RR_HIP(hipEventRecord(ctx->kev[(size_t)ctx->kev_used * 2], ctx->stream));
     }
-#ifdef RR_EXPERIMENTAL
-    if (wavefront) RR_HIP(launch_render_wavefront(sc, a, ctx->wf, stack_sel, ctx->stream));
-    else if (refill_kernel) RR_HIP(launch_render_refill(sc, a, (int)need, stats, ctx->stream, refill_stack16));
-    else if (scene_async) RR_HIP(launch_render_scene_async(sc, a, (int)need, stats, ctx->stream, refill_stack16));
-    else if (scene_stream) RR_HIP(launch_render_scene_stream(sc, a, ctx->d_tickets + (size_t)rr_context::MAX_LANES * LDS_TICKET_WORDS, ctx->n_cus,
-                                                             ctx->dbg_stream_waves, stats, ctx->stream));
-    else if (ctx->dbg_kernel == 2 && ctx->single_identity) RR_HIP(launch_render_async(sc, a, stack_sel, p.max_reflect <= 2 ? 2 : 8, stats, ctx->stream));
-    else
-#endif
     if (stream_kernel) { if (int r = launch_stream(stats)) return r; }
     else if (paths_kernel) { if (int r = launch_paths(stats)) return r; }
     else if (lds_kernel) { if (int r = launch_lds(stats)) return r; }
@@ -1199,8 +1157,8 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         (void)hipFree(d_diag);
         if (FILE* f = fopen(diag_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
-    snprintf(ctx->last_kernel_name, sizeof ctx->last_kernel_name, "%s", stream_kernel ? last_stream_kernel_name() : (wavefront || refill_kernel || scene_async || scene_stream) ? "(experiment)" : last_render_kernel_name());
-    ctx->last_kernel = stream_kernel ? 7u : wavefront ? 3u : paths_kernel ? 2u : refill_kernel ? 4u : scene_async ? 5u : scene_stream ? 6u : lds_kernel ? 1u : 0u;
+    snprintf(ctx->last_kernel_name, sizeof ctx->last_kernel_name, "%s", stream_kernel ? last_stream_kernel_name() : last_render_kernel_name());
+    ctx->last_kernel = stream_kernel ? 7u : paths_kernel ? 2u : lds_kernel ? 1u : 0u;
     ctx->W = width; ctx->H = height; ctx->frame_world = ctx->tile_world; ctx->frame_depth = depth;
     ctx->have_f32 = want_f32; ctx->have_frame = ext_tiles == nullptr; ctx->have_assembled = false;
     if (!ext_tiles) ctx->frame_base = out_base;
@@ -1523,7 +1481,7 @@ namespace {
 struct Rccl {
     void* lib = nullptr;
     int (*GetUniqueId)(void*) = nullptr;
-    int (*CommInitRank)(void**, int, ncclUniqueId, int) = nullptr;
+    int (*CommInitRank)(void**, int, rr_nccl_unique_id, int) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
@@ -1550,7 +1508,7 @@ struct Rccl {
     }
 };
 extern "C++" const Rccl& rccl() { static const Rccl r; return r; }      // (this translation unit's tail is inside extern "C")
-static_assert(sizeof(ncclUniqueId) == 128, "rr_comm_unique_id hands out 128 bytes");
+static_assert(sizeof(rr_nccl_unique_id) == 128, "rr_comm_unique_id hands out 128 bytes");
 } // namespace
 
 int rr_comm_unique_id(void* id128)
@@ -1565,7 +1523,7 @@ int rr_comm_init(rr_context* ctx, const void* id128, int rank, int world, void**
     if (int r = use_device(ctx)) return r;                        // the communicator belongs to the context's device
     if (!id128 || !comm || world < 1 || rank < 0 || rank >= world) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_comm_init: bad arguments");
     if (!rccl().ok) return fail(ctx, RR_ERR_UNSUPPORTED, "rr_comm_init: librccl.so not found");
-    ncclUniqueId id;
+    rr_nccl_unique_id id;
     memcpy(&id, id128, sizeof id);
     *comm = nullptr;
     const int e = rccl().CommInitRank(comm, world, id, rank);
@@ -1590,10 +1548,10 @@ int rr_gather_frames(rr_context* ctx, void* comm, int rank, int world, const voi
     if (bytes_per_rank == 0) return RR_OK;
     const Rccl& R = rccl();
     int e = R.GroupStart();
-    if (e == 0) e = R.Send(d_send, (size_t)bytes_per_rank, (int)ncclUint8, root, comm, ctx->stream);
+    if (e == 0) e = R.Send(d_send, (size_t)bytes_per_rank, (int)RR_NCCL_UINT8, root, comm, ctx->stream);
     if (rank == root)
         for (int r = 0; r < world && e == 0; ++r)
-            e = R.Recv((char*)d_recv + (size_t)r * bytes_per_rank, (size_t)bytes_per_rank, (int)ncclUint8, r, comm, ctx->stream);
+            e = R.Recv((char*)d_recv + (size_t)r * bytes_per_rank, (size_t)bytes_per_rank, (int)RR_NCCL_UINT8, r, comm, ctx->stream);
     const int e2 = R.GroupEnd();
     if (e == 0) e = e2;
     if (e != 0) { ctx->err = std::string("rr_gather_frames: ") + (R.GetErrorString ? R.GetErrorString(e) : "RCCL error"); return RR_ERR_DEVICE; }

@@ -39,28 +39,6 @@ hipError_t launch_assemble_frames_rgb8(const uint8_t* gathered, uint32_t* frames
                                        uint32_t world, size_t rank_stride_b, size_t frame_stride_b, size_t out_stride, uint32_t n_frames,
                                        hipStream_t s);
 
-// ---- experiments (rr_render_exp.hip, only in builds made with RR_EXPERIMENTAL=1; RR_DEBUG_KERNEL selects them) ----------
-// queue-per-bounce renderer (single identity instance, max_reflect <= 2): ray queues (48 B records, ping-pong), four
-// (w, texel) slots per pixel, the list of covered pixels
-struct WfBuffers {
-    float4*   q[2];        // cap records of 3 x float4 each
-    float4*   slots;       // [pixel index][4]: one slot per leaf of the pixel's ray tree, in depth-first order
-    uint32_t* hit_list;    // pixel indices whose primary ray hit
-    uint32_t* counts;      // [0] unused, [g] rays queued for bounce g (1..62), [63] covered pixels
-    uint32_t  cap;         // queue capacity in rays
-};
-#ifdef RR_EXPERIMENTAL
-hipError_t launch_render_wavefront(const SceneDev& sc, const DispatchDev& a, const WfBuffers& wf, int stack, hipStream_t s);
-// lane-asynchronous form of k_render_fused (single identity instance)
-hipError_t launch_render_async(const SceneDev& sc, const DispatchDev& a, int stack, int pend, bool stats, hipStream_t s);
-// pixel refill (k_render_refill): a wave's lanes take the next pixel of its 256-pixel column as theirs finish
-hipError_t launch_render_refill(const SceneDev& sc, const DispatchDev& a, int stack, bool stats, hipStream_t s, bool stack16);
-// scenes with a TLAS: lane-asynchronous renderer (k_render_scene_async)
-hipError_t launch_render_scene_async(const SceneDev& sc, const DispatchDev& a, int stack, bool stats, hipStream_t s, bool stack16);
-// the same as a streaming kernel (k_render_scene_stream): persistent waves, one ticket word for the launch
-hipError_t launch_render_scene_stream(const SceneDev& sc, const DispatchDev& a, uint32_t* ticket, int n_cus, int waves, bool stats, hipStream_t s);
-#endif
-
 // ---- rr_bvh_build.hip
 // Scratch + outputs of one LBVH build over n primitives (triangles of a mesh, or instances).
 struct BuildBuffers {

@@ -1,5 +1,4 @@
-// rr_render_common.h -- device code shared by the render kernels (rr_render.hip and, in builds with RR_EXPERIMENTAL, the
-// experiments of rr_render_exp.hip): a pixel's ray tree as the lanes walk it (RayGen, ClosestHit / Miss, the parked
+// rr_render_common.h -- device code shared by the render kernels (rr_render.hip, rr_render_stream.hip): a pixel's ray tree as the lanes walk it (RayGen, ClosestHit / Miss, the parked
 // reflected rays), the frame store, the counters, and the numbering of a dispatch's 8x8 pixel blocks.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -125,7 +125,7 @@ struct DispatchDev {
     // divisions (exact below 65 536 tiles).
     uint32_t rt_x0, rt_y0, rt_w, rt_h, rt_div_w, rt_div_o;
     uint32_t group_trace;           // k_render_paths: 1 = ray levels with few rays left are traced by groups of 2 / 4 lanes per ray (trace_blas_group)
-    uint32_t async_leaf_num, async_shade_num;   // k_render_scene_async: a leaf step once leaf lanes * 8 >= travelling lanes * num; a shading pass once finished lanes * 8 >= live lanes * num
+    uint32_t async_leaf_num, async_shade_num;   // k_stream_rays: lanes (in sixteenths of the live lanes) a step / a shading pass needs to be issued
     uint32_t* out_rgba8;            // world==1: W*H raster; else compact tiles
     float4*   out_f32;              // optional, same addressing
     unsigned long long* counters;   // rr::Counter slots

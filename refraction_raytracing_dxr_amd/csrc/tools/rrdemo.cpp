@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include <signal.h>
 #include <spawn.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
@@ -21,14 +22,17 @@
 extern char** environ;
 
 // --gpus N: this process only starts N copies of itself (ranks 0..N-1, device = --device + rank) and waits for them; it never
-// touches a GPU.  Rank 0 makes the RCCL id and leaves it in a file the others wait for.
+// touches a GPU.  Rank 0 makes the RCCL id and leaves it in a file the others wait for; the file lives in a directory only this
+// user can enter (mkdtemp, mode 0700), so nobody else on the machine can plant it or a link in its place.  When a rank fails
+// -- or cannot be started -- the others are ended too: they would wait in RCCL for it for ever.
 static int launch_ranks(int argc, char** argv, int gpus)
 {
-    char idfile[256];
-    snprintf(idfile, sizeof idfile, "/tmp/rrdemo_id_%d", (int)getpid());
-    unlink(idfile);
+    char dir[] = "/tmp/rrdemo.XXXXXX";
+    if (!mkdtemp(dir)) { perror("mkdtemp"); return 1; }
+    const std::string idfile = std::string(dir) + "/id";
     std::vector<pid_t> pids;
-    for (int r = 0; r < gpus; ++r) {
+    bool ok = true;
+    for (int r = 0; r < gpus && ok; ++r) {
         std::vector<std::string> a(argv, argv + argc);
         a.push_back("--rank"); a.push_back(std::to_string(r));
         a.push_back("--id-file"); a.push_back(idfile);
@@ -36,16 +40,27 @@ static int launch_ranks(int argc, char** argv, int gpus)
         for (auto& x : a) av.push_back(const_cast<char*>(x.c_str()));
         av.push_back(nullptr);
         pid_t pid;
-        if (posix_spawn(&pid, "/proc/self/exe", nullptr, nullptr, av.data(), environ) != 0) { fprintf(stderr, "cannot start rank %d\n", r); break; }
+        if (posix_spawn(&pid, "/proc/self/exe", nullptr, nullptr, av.data(), environ) != 0) { fprintf(stderr, "cannot start rank %d\n", r); ok = false; break; }
         pids.push_back(pid);
     }
-    int worst = (int)pids.size() == gpus ? 0 : 1;
-    for (pid_t pid : pids) {
+    size_t left = pids.size();
+    std::vector<bool> done(pids.size(), false);
+    auto end_the_rest = [&] { for (size_t i = 0; i < pids.size(); ++i) if (!done[i]) kill(pids[i], SIGTERM); };
+    if (!ok) end_the_rest();
+    while (left > 0) {
         int st = 0;
-        if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) worst = 1;
+        const pid_t pid = waitpid(-1, &st, 0);
+        if (pid < 0) { ok = false; break; }
+        for (size_t i = 0; i < pids.size(); ++i)
+            if (pids[i] == pid && !done[i]) {
+                done[i] = true; --left;
+                if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) { if (ok) end_the_rest(); ok = false; }
+            }
     }
-    unlink(idfile);
-    return worst;
+    unlink(idfile.c_str());
+    unlink((idfile + ".tmp").c_str());
+    rmdir(dir);
+    return ok ? 0 : 1;
 }
 
 int main(int argc, char** argv)

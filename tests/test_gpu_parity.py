@@ -31,14 +31,6 @@ def gpu():
     r.close()
 
 
-def experimental_build():
-    """True when librrdxr.so was built with RR_EXPERIMENTAL=1 (the render-kernel experiments of csrc/rr_render_exp.hip)."""
-    try:
-        return "-DRR_EXPERIMENTAL" in open(os.path.join(ROOT, "refraction_raytracing_dxr_amd", "build", "flags.txt")).read()
-    except OSError:
-        return False
-
-
 def load(name):
     m = rr.Mesh()
     assert m.load(O.asset(name))
@@ -318,35 +310,6 @@ def test_unorm8_store_edges_through_dispatch_rays(gpu):
     assert rgba_t[..., :3].max() == 255 and (rgba_t[..., :3][np.isinf(x) & (x > 0)] == 255).all()      # +inf -> 1
 
 
-@pytest.mark.skipif(not experimental_build(), reason="the product library does not contain the experiments (build with RR_EXPERIMENTAL=1)")
-def test_experimental_wavefront_kernels_render_the_same_frames(tmp_path):
-    """RR_DEBUG_KERNEL=wavefront (queue-per-bounce kernels kept for comparison): bit-identical frames to
-    the fused kernel, whatever order the queues fill in.  Own processes: the switch is read once per process."""
-    import subprocess
-    import sys
-    code = (
-        "import sys, numpy as np\n"
-        "sys.path.insert(0, %r)\n"
-        "import refraction_raytracing_dxr_amd as rr\n"
-        "from refraction_raytracing_dxr_amd.synth import asset, procedural_env\n"
-        "r = rr.Renderer(0); out = []\n"
-        "for name, kw in (('monkey.obj', dict(max_refract=8)), ('sphere.obj', dict(max_refract=4, max_reflect=1)), ('cube.obj', dict())):\n"
-        "    m = rr.Mesh(); m.load(asset(name))\n"
-        "    r.load_scene(m.verts, m.indices, procedural_env(256, 128, seed=9))\n"
-        "    r.render_orbit(323, 181, 5, angle=0.3, params=rr.default_params(**kw), frames_per_dispatch=3)\n"
-        "    out += [r.read_frame(slice=0), r.read_frame(slice=1)]\n"
-        "    assert r.stats().traversal_overflow == 0\n"
-        "np.save(sys.argv[1], np.stack(out)); print(r.stats().rays)\n") % ROOT
-    res = {}
-    for k in ("fused", "wavefront"):
-        env = dict(os.environ, RR_DEBUG_KERNEL=k)
-        p = subprocess.run([sys.executable, "-c", code, str(tmp_path / (k + ".npy"))], capture_output=True, text=True, env=env, timeout=300)
-        assert p.returncode == 0, p.stderr[-2000:]
-        res[k] = (np.load(tmp_path / (k + ".npy")), int(p.stdout.split()[-1]))
-    assert np.array_equal(res["fused"][0], res["wavefront"][0])
-    assert res["fused"][1] == res["wavefront"][1]                      # and the same number of TraceRay calls
-
-
 def test_lds_and_path_parallel_kernels_render_the_same_frames(tmp_path):
     """k_render_lds (persistent workgroups, BLAS nodes in LDS, tickets, reflected rays parked in memory) and k_render_paths
     (four lanes per pixel, one per root-to-leaf path of the ray tree) against k_render_fused: every frame byte for byte, float colours bit for bit, the same counters --
@@ -376,8 +339,7 @@ def test_lds_and_path_parallel_kernels_render_the_same_frames(tmp_path):
         "np.save(sys.argv[1], np.stack(out)); print(' '.join(str(c) for c in cnt))\n") % ROOT
     res = {}
     for k, extra in (("fused", {}), ("lds", {}), ("lds", {"RR_DEBUG_SHAPE": "1"}), ("lds", {"RR_DEBUG_SHAPE": "2", "RR_DEBUG_TICKET": "19"}),
-                     ("paths", {})) + (         # k_render_paths: four lanes per pixel, leaves summed in the recursion's order
-                     (("refill", {}),) if experimental_build() else ()):     # experiment, same bar
+                     ("paths", {})):            # k_render_paths: four lanes per pixel, leaves summed in the recursion's order
         env = dict(os.environ, RR_DEBUG_KERNEL=k, **extra)
         tag = k + "".join(extra.values())
         p = subprocess.run([sys.executable, "-c", code, str(tmp_path / (tag + ".npy"))], capture_output=True, text=True, env=env, timeout=600)

@@ -82,3 +82,29 @@ def test_malformed_objs_never_trip_the_sanitizers(driver, tmp_path):
     for mode in ("obj", "objx"):
         ok, refused = run(driver, mode, files)
         assert ok + refused == len(files)
+
+
+def test_interlaced_pngs_never_trip_the_sanitizers(driver, tmp_path):
+    """The Adam7 de-interlace path parses untrusted files too: interlaced PNGs of every sample depth (1, 2, 4, 8, 16 bits;
+    gray, gray+alpha, RGB, RGBA, palette), 1 x N and N x 1 images (most of the seven passes empty), truncations at every
+    kind of offset and seeded bit-flips of all of them, through the ASan + UBSan build: decoded or refused, never a report."""
+    from test_host import _adam7_cases, _write_adam7_png
+    rng = np.random.default_rng(12)
+    cases = dict(_adam7_cases(rng))
+    cases.update({
+        "i_1xN.png": (rng.integers(0, 256, (23, 1, 3), dtype=np.uint8), 8, None),
+        "i_Nx1.png": (rng.integers(0, 256, (1, 29, 3), dtype=np.uint8), 8, None),
+        "i_g1_1xN.png": (rng.integers(0, 2, (17, 1), dtype=np.uint8), 1, None),
+        "i_g2_Nx1.png": (rng.integers(0, 4, (1, 13), dtype=np.uint8), 2, None),
+        "i_g4.png": (rng.integers(0, 16, (9, 10), dtype=np.uint8), 4, None),
+    })
+    valid, files = [], []
+    for k, (name, (arr, depth, pal)) in enumerate(sorted(cases.items())):
+        path = str(tmp_path / name)
+        _write_adam7_png(path, arr, depth, pal)
+        valid.append(path)
+        files += mutations(path, str(tmp_path), 12, 25, seed=100 + k)
+    ok, refused = run(driver, "img", valid)
+    assert ok == 5 * len(valid) and refused == 0
+    ok, refused = run(driver, "img", files)
+    assert ok + refused == 5 * len(files) and refused > 0
