@@ -252,6 +252,9 @@ def main():
     ap.add_argument("--rotate-root", action="store_true",
                     help="N>1: gather batch b to rank b %% N instead of rank 0 (frames end up spread over the ranks; "
                          "no single GPU takes in every frame).  Off by default: the reference presents from one device")
+    ap.add_argument("--round-robin-tiles", action="store_true",
+                    help="N>1: deal every tile of the frame round robin and gather them all (round 2's partition) instead of only "
+                         "the tiles that touch the scene's screen rectangle")
     ap.add_argument("--frames-per-dispatch", type=int, default=64,
                     help="depth slices per launch (DispatchRays(W,H,Depth)); N>1: also frames per RCCL gather")
     args = ap.parse_args()
@@ -273,13 +276,22 @@ def main():
         local_rank = 0                      # rehearsal: every rank shares the one card
     torch.cuda.set_device(local_rank)
     dist = None
+    # RCCL prints a version banner to STDOUT when its first communicator comes up; the driver reads one JSON line from there.
+    # While the process group is set up (and its first collective runs) file descriptor 1 points at stderr.
+    class _StdoutToStderr:
+        def __enter__(self):
+            sys.stdout.flush(); self.saved = os.dup(1); os.dup2(2, 1); return self
+        def __exit__(self, *exc):
+            sys.stdout.flush(); os.dup2(self.saved, 1); os.close(self.saved)
     if world > 1:
         import torch.distributed as dist
         backend = os.environ.get("RR_BENCH_BACKEND", "nccl")      # "gloo" only to rehearse the N>1 path on a 1-GPU box
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=backend)
+        with _StdoutToStderr():
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend=backend)
+            dist.barrier()
 
     mesh = rr.Mesh()
     assert mesh.load(asset("monkey.obj"))
@@ -301,7 +313,9 @@ def main():
     if force_sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        with _StdoutToStderr():
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            dist.barrier()
     if world == 1 and not force_sharded:
         r.set_tile_partition(0, 1)
         if args.prewarm > 0:
@@ -324,16 +338,20 @@ def main():
         # a run shorter than two such batches is split in two, so that the gather of the first half travels under the render of
         # the second and the de-interleave of the first under the gather of the second (one batch overlaps nothing)
         Fn = max(1, min(Fn, (K + 1) // 2))
+        # only the tiles that touch the scene's screen rectangle are dealt to the ranks and gathered; rank 0 renders the background
+        # tiles itself (rr_mesh_partition): 72 instead of 255 tiles per rank and frame at N = 8 on this view
         sf = rr.dist.ShardedFrames(r, W, H, rank, world, torch.device("cuda", local_rank), Fn, always_collective=force_sharded,
-                                   rotate_root=args.rotate_root)
+                                   rotate_root=args.rotate_root, mesh_partition=not args.rotate_root and not args.round_robin_tiles)
         if args.prewarm > 0:
             sf.render_orbit(args.prewarm, angle=0.01, params=params)
         sf.render_orbit(Wm, angle=0.01, params=params)
         barrier()
         t0 = time.perf_counter()
+        sf.gathered_bytes = 0
         rays_local = sf.render_orbit(K, angle=0.01, params=params)
         barrier()
         elapsed = time.perf_counter() - t0
+        gathered_bytes = sf.gathered_bytes
         region_ms = None
         # attribution of the N-GPU figure (untimed extra): every rank's share of the same frames rendered without the gather
         # and the de-interleave -- if the end-to-end time is far above the slowest rank's render time, the rest is rank 0's
@@ -523,7 +541,8 @@ def main():
             "config": {"workload": "monkey.obj (967 tri) 1920x1080, 8 refraction / 2 reflection bounces, ior 1.3, "
                                    "orbit angle 0.01*(k+1), seeded procedural 2048x1024 RGB32F env map",
                        "rays_per_frame": round(total_rays / K, 1),
-                       "parallelism": "tiles32x32-roundrobin-x%d%s" % (world, "-rotating-root" if args.rotate_root and world > 1 else ""),
+                       "parallelism": "tiles32x32-%s-x%d%s" % ("roundrobin" if (args.round_robin_tiles or args.rotate_root or world == 1) else "meshtiles-roundrobin",
+                                                                 world, "-rotating-root" if args.rotate_root and world > 1 else ""),
                        "frames_per_dispatch": min(K, F) if world == 1 and not force_sharded else Fn,
                        "prewarm_steps": args.prewarm,
                        "launch_shape": "DispatchRays(W, H, Depth = frames_per_dispatch): every frame complete in its own buffer; the "
@@ -532,6 +551,9 @@ def main():
             "multi_gpu_attribution": None if world == 1 and not force_sharded else {
                 "end_to_end_ms_per_step": round(elapsed / K * 1e3, 5),
                 "render_only_ms_per_step_by_rank": [round(x / K * 1e3, 5) for x in render_only_all],
+                "tile_partition": "round-robin over all tiles" if (args.round_robin_tiles or args.rotate_root) else
+                                  "mesh tiles round-robin, background tiles on rank 0 (rr_mesh_partition)",
+                "gathered_bytes_per_rank_per_step": int(gathered_bytes / K),
                 "note": "render_only: each rank's tiles of the same frames, same launches and lanes, no gather, no de-interleave "
                         "(untimed extra pass).  end_to_end - max(render_only) = rank 0's gather ingest + assemble that the pipeline "
                         "did not hide"},

@@ -256,6 +256,27 @@ int  rr_render_orbit_sharded_lane(rr_context* ctx, uint32_t width, uint32_t heig
                                   float fov_y, float aspect, float zn, float zf,
                                   void* d_tiles, uint64_t frame_stride_bytes, uint32_t lane);
 int  rr_lane_join(rr_context* ctx, uint32_t lane);
+/* Multi-GPU tile partition that only moves what has to move (see rr_host_mesh_partition below) */
+typedef struct rr_mesh_partition {
+    uint32_t tiles_x, n_tiles;
+    uint32_t rect_x0, rect_y0, rect_w, rect_h;      /* in tiles */
+    uint32_t n_mesh_tiles, n_bg_tiles, max_mesh_tiles_per_rank, world;
+} rr_mesh_partition;
+/* The mesh-tile partition for a sharded context, one DispatchRays(W, H, n_frames) per call:
+ * rr_mesh_partition_for_orbit says how the n_frames frames starting at `angle` will be dealt (the rectangle is the union over
+ * their cameras; the same on every rank), so that the caller can size its buffers: frame f's mesh tiles of this rank go to
+ * d_mesh_tiles + f * mesh_stride_bytes (slot s at s * 3072: RGB8, max_mesh_tiles_per_rank slots, unused ones zeroed) -- the send
+ * buffer of the gather --, and on rank 0 its background tiles to d_bg_tiles + f * bg_stride_bytes (n_bg_tiles slots; other
+ * ranks pass NULL).  rr_assemble_frames_mesh_rgb8 puts gathered mesh tiles and rank 0's background tiles back into rasters. */
+int  rr_mesh_partition_for_orbit(rr_context* ctx, uint32_t width, uint32_t height, float angle, float angle_step, uint32_t n_frames,
+                                 float fov_y, float aspect, float zn, float zf, rr_mesh_partition* out);
+int  rr_render_orbit_mesh_sharded_lane(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispatch_params* params,
+                                       float* angle, float angle_step, uint32_t n_frames, float fov_y, float aspect, float zn, float zf,
+                                       void* d_mesh_tiles, uint64_t mesh_stride_bytes, void* d_bg_tiles, uint64_t bg_stride_bytes,
+                                       uint32_t lane);
+int  rr_assemble_frames_mesh_rgb8(rr_context* ctx, const void* d_gathered, uint64_t rank_stride_bytes, uint64_t frame_stride_bytes,
+                                  const void* d_bg_tiles, uint64_t bg_stride_bytes, const rr_mesh_partition* part, uint32_t n_frames,
+                                  uint32_t width, uint32_t height, void* d_frames, uint64_t out_stride_bytes);
 /* ---- the final image gather, natively (north star: "host stays C++ ... final RCCL gather over xGMI") --------------------
  * The reference has one adapter and no collective (RefractionDemo.cpp:163 NodeMask 0); here every rank renders its
  * tiles and ONE gather per batch of frames brings them to the root.  RCCL is looked up at run time (dlopen of
@@ -328,6 +349,18 @@ int  rr_download_qnodes(rr_context* ctx, uint32_t mesh_id, void* qnodes, uint32_
 
 /* ---- pure host helpers (no device, no context) --------------------------------------------- */
 void rr_default_dispatch_params(rr_dispatch_params* p);
+/* Where the box {lo[3], hi[3]} can be seen at all with any of the n constants (GenerateCameraRay, RayTracing.hlsl:27-40):
+ * rect = {x0, y0, x1, y1} in pixels, aligned outward to 8 with 8 pixels of margin; the whole frame whenever the projection
+ * cannot be trusted (camera inside or beside the box, singular or badly conditioned proj_inv, constants == NULL).  The render
+ * kernels shade blocks outside it as one Miss without TraceRay. */
+int  rr_host_screen_rect(const float bounds[6], const rr_scene_constants* constants, uint32_t n, uint32_t width, uint32_t height,
+                         uint32_t rect[4]);
+/* Multi-GPU tile partition that only moves what has to move: the tiles that touch the rectangle ("mesh tiles", raster order
+ * inside the rectangle, index i) belong to rank i % world, slot i / world of that rank's tile buffer; all the other tiles
+ * ("background tiles": one Miss per pixel, a tenth of the work and two thirds of the bytes of the reference's views) belong to
+ * rank 0, in raster order, and never cross a link.  rect_w == 0: no usable rectangle, every tile is a mesh tile. */
+int  rr_host_mesh_partition(const float bounds[6], const rr_scene_constants* constants, uint32_t n, uint32_t width, uint32_t height,
+                            uint32_t world, rr_mesh_partition* out);
 /* RefractionDemo.cpp:559-566: camera constants for an orbit angle.  The reference's literals are
  * fov_y = float(52.0/180.0*3.1415), aspect = 1.333f, zn = 1, zf = 125; frame k uses angle 0.01*(k+1). */
 int  rr_host_camera_orbit(float angle, float fov_y, float aspect, float zn, float zf,

@@ -12,7 +12,7 @@ LIB = os.path.join(PKG, "librrdxr.so")
 DEMO = os.path.join(PKG, "rrdemo")
 
 DEVICE_SOURCES = ["rr_bvh_build.hip", "rr_render.hip", "rr_render_stream.hip"]
-HOST_SOURCES = ["rr_capi.cpp", "host/rr_host_camera.cpp", "host/rr_host_mesh.cpp", "host/rr_host_image.cpp",
+HOST_SOURCES = ["rr_capi.cpp", "host/rr_host_camera.cpp", "host/rr_host_mesh.cpp", "host/rr_host_image.cpp", "host/rr_host_partition.cpp",
                 "host/Mesh.cpp", "host/RefractionDemo.cpp"]
 HEADERS = ["rr_types.h", "rr_device.h", "rr_launch.h", "rr_render_common.h", "host/Mesh.hpp", "host/RefractionDemo.hpp",
            "../../include/rrdxr.h"]

@@ -68,6 +68,13 @@ class Stats(C.Structure):
         return self.clock_ticks / self.clock_ref_ticks * 0.1 if self.clock_ref_ticks else 0.0
 
 
+class MeshPartition(C.Structure):
+    """rr_mesh_partition: mesh tiles dealt round robin, background tiles to rank 0"""
+    _fields_ = [("tiles_x", C.c_uint32), ("n_tiles", C.c_uint32), ("rect_x0", C.c_uint32), ("rect_y0", C.c_uint32),
+                ("rect_w", C.c_uint32), ("rect_h", C.c_uint32), ("n_mesh_tiles", C.c_uint32), ("n_bg_tiles", C.c_uint32),
+                ("max_mesh_tiles_per_rank", C.c_uint32), ("world", C.c_uint32)]
+
+
 # every symbol include/rrdxr.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = {
@@ -104,6 +111,13 @@ SYMBOLS = {
                                                C.c_float, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float,
                                                _P, C.c_uint64, C.c_uint32]),
     "rr_lane_join": (C.c_int, [_P, C.c_uint32]),
+    "rr_mesh_partition_for_orbit": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_uint32, C.c_float, C.c_float, C.c_float,
+                                              C.c_float, C.POINTER(MeshPartition)]),
+    "rr_render_orbit_mesh_sharded_lane": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(DispatchParams), C.POINTER(C.c_float), C.c_float,
+                                                    C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float, _P, C.c_uint64, _P, C.c_uint64,
+                                                    C.c_uint32]),
+    "rr_assemble_frames_mesh_rgb8": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, _P, C.c_uint64, C.POINTER(MeshPartition), C.c_uint32, C.c_uint32,
+                                               C.c_uint32, _P, C.c_uint64]),
     "rr_set_frames_in_flight": (C.c_int, [_P, C.c_uint32]),
     "rr_assemble_frames": (C.c_int, [_P, _P, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                      _P, C.c_uint64]),
@@ -127,6 +141,9 @@ SYMBOLS = {
     "rr_download_qnodes": (C.c_int, [_P, C.c_uint32, _P, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
     "rr_default_dispatch_params": (None, [C.POINTER(DispatchParams)]),
     "rr_host_camera_orbit": (C.c_int, [C.c_float] * 5 + [C.POINTER(SceneConstants)]),
+    "rr_host_screen_rect": (C.c_int, [C.POINTER(C.c_float), C.POINTER(SceneConstants), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "rr_host_mesh_partition": (C.c_int, [C.POINTER(C.c_float), C.POINTER(SceneConstants), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.POINTER(MeshPartition)]),
     "rr_host_mesh_load_obj": (C.c_int, [C.c_char_p, C.POINTER(_P), C.POINTER(C.c_uint32), C.POINTER(_P),
                                         C.POINTER(C.c_uint32)]),
     "rr_host_mesh_load_obj_ex": (C.c_int, [C.c_char_p, C.c_uint32, C.POINTER(_P), C.POINTER(C.c_uint32), C.POINTER(_P),

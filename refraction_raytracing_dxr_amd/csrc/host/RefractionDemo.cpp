@@ -123,35 +123,43 @@ int pumpSharded(int n_frames, int frames_per_gather, rr_stats* stats)
     if (!g_ctx || !g_comm) return fail(RR_ERR_STATE, "initializeSharded first");
     if (n_frames <= 0 || frames_per_gather <= 0) return fail(RR_ERR_INVALID_ARGUMENT, "pumpSharded: frame counts must be positive");
     const uint32_t W = (uint32_t)g_opt.width, H = (uint32_t)g_opt.height;
-    uint32_t n_local = 0, max_tiles = 0;
-    int rc = rr_local_tile_count(g_ctx, W, H, &n_local, &max_tiles);
-    if (rc != RR_OK) return fail(rc, "rr_local_tile_count");
-    const uint64_t frame_stride = (uint64_t)max_tiles * 32 * 32 * 4;              // one rank's tiles of one frame, RGBA8
-    const uint64_t batch_bytes = frame_stride * (uint64_t)frames_per_gather;      // what every rank contributes per gather
+    // The mesh-tile partition (rr_mesh_partition): only the tiles that touch the scene's screen rectangle are dealt to the ranks
+    // and gathered; rank 0 renders the background tiles itself.  Buffers are sized for a batch whose rectangle is the whole
+    // frame; a batch moves max_mesh_tiles_per_rank tiles per frame and rank.
+    const uint32_t n_tiles = ((W + 31u) / 32u) * ((H + 31u) / 32u);
+    const uint64_t tile_bytes = 32 * 32 * 3;                                      // RGB8
+    const uint64_t rank_stride = (uint64_t)((n_tiles + (uint32_t)g_world - 1u) / (uint32_t)g_world) * tile_bytes * (uint64_t)frames_per_gather;
+    const uint64_t bg_bytes = (uint64_t)n_tiles * tile_bytes * (uint64_t)frames_per_gather;
     const uint64_t raster = (uint64_t)W * H * 4;
     // Two buffer sets and two render lanes: batch b is rendered on lane b % 2 into set b % 2 while the gather of batch b - 1
     // (queued on the context's stream behind that lane's join) and its de-interleave run -- the gather travels under the next
     // render instead of after it.  Set b % 2 is free again when batch b + 2 starts: the context's stream, on which gather and
     // de-interleave of batch b were queued, is what lane b % 2 forks from.
-    void *d_send[2] = { nullptr, nullptr }, *d_recv[2] = { nullptr, nullptr }, *d_frames = nullptr;
-    auto release = [&] { for (int k = 0; k < 2; ++k) { rr_device_free(g_ctx, d_send[k]); rr_device_free(g_ctx, d_recv[k]); } rr_device_free(g_ctx, d_frames); };
+    void *d_send[2] = { nullptr, nullptr }, *d_recv[2] = { nullptr, nullptr }, *d_bg[2] = { nullptr, nullptr }, *d_frames = nullptr;
+    auto release = [&] { for (int k = 0; k < 2; ++k) { rr_device_free(g_ctx, d_send[k]); rr_device_free(g_ctx, d_recv[k]); rr_device_free(g_ctx, d_bg[k]); } rr_device_free(g_ctx, d_frames); };
+    int rc = RR_OK;
     for (int k = 0; k < 2 && rc == RR_OK; ++k) {
-        rc = rr_device_alloc(g_ctx, batch_bytes, &d_send[k]);
-        if (rc == RR_OK && g_rank == 0) rc = rr_device_alloc(g_ctx, batch_bytes * (uint64_t)g_world, &d_recv[k]);
+        rc = rr_device_alloc(g_ctx, rank_stride, &d_send[k]);
+        if (rc == RR_OK && g_rank == 0) rc = rr_device_alloc(g_ctx, rank_stride * (uint64_t)g_world, &d_recv[k]);
+        if (rc == RR_OK && g_rank == 0) rc = rr_device_alloc(g_ctx, bg_bytes, &d_bg[k]);
     }
     if (rc == RR_OK && g_rank == 0) rc = rr_device_alloc(g_ctx, raster * (uint64_t)frames_per_gather, &d_frames);
     if (rc != RR_OK) { release(); return fail(rc, "rr_device_alloc"); }
     rr_dispatch_params p = g_opt.dispatch;
     int last_n = 0, pending_n = 0, pending_set = -1;
+    rr_mesh_partition pending_part;
+    std::memset(&pending_part, 0, sizeof pending_part);
     auto gather_pending = [&]() -> int {            // join the lane of the batch launched before, gather it, de-interleave on rank 0
         if (pending_set < 0) return RR_OK;
+        const uint64_t frame_stride = (uint64_t)pending_part.max_mesh_tiles_per_rank * tile_bytes;
         int r = rr_lane_join(g_ctx, (uint32_t)pending_set);
         if (r != RR_OK) return fail(r, "rr_lane_join");
-        r = rr_gather_frames(g_ctx, g_comm, g_rank, g_world, d_send[pending_set], d_recv[pending_set], batch_bytes, 0);
+        r = rr_gather_frames(g_ctx, g_comm, g_rank, g_world, d_send[pending_set], d_recv[pending_set], frame_stride * (uint64_t)pending_n, 0);
         if (r != RR_OK) return fail(r, "rr_gather_frames");
         if (g_rank == 0) {
-            r = rr_assemble_frames(g_ctx, d_recv[pending_set], (uint32_t)g_world, batch_bytes, frame_stride, (uint32_t)pending_n, W, H, d_frames, raster);
-            if (r != RR_OK) return fail(r, "rr_assemble_frames");
+            r = rr_assemble_frames_mesh_rgb8(g_ctx, d_recv[pending_set], frame_stride * (uint64_t)pending_n, frame_stride, d_bg[pending_set],
+                                             (uint64_t)pending_part.n_bg_tiles * tile_bytes, &pending_part, (uint32_t)pending_n, W, H, d_frames, raster);
+            if (r != RR_OK) return fail(r, "rr_assemble_frames_mesh_rgb8");
         }
         last_n = pending_n; pending_set = -1;
         return RR_OK;
@@ -160,11 +168,15 @@ int pumpSharded(int n_frames, int frames_per_gather, rr_stats* stats)
     for (int k = 0; k < n_frames && rc == RR_OK; k += frames_per_gather, ++b) {
         const int n = n_frames - k < frames_per_gather ? n_frames - k : frames_per_gather;
         if (k > 0) p.flags |= RR_DISPATCH_KEEP_COUNTERS;
-        rc = rr_render_orbit_sharded_lane(g_ctx, W, H, &p, &g_angle, g_opt.angle_step, (uint32_t)n, (uint32_t)n, g_opt.fov_y, g_opt.aspect,
-                                          g_opt.zn, g_opt.zf, d_send[b & 1], frame_stride, (uint32_t)(b & 1));
-        if (rc != RR_OK) { fail(rc, "rr_render_orbit_sharded_lane"); break; }
+        rr_mesh_partition part;
+        rc = rr_mesh_partition_for_orbit(g_ctx, W, H, g_angle, g_opt.angle_step, (uint32_t)n, g_opt.fov_y, g_opt.aspect, g_opt.zn, g_opt.zf, &part);
+        if (rc != RR_OK) { fail(rc, "rr_mesh_partition_for_orbit"); break; }
+        rc = rr_render_orbit_mesh_sharded_lane(g_ctx, W, H, &p, &g_angle, g_opt.angle_step, (uint32_t)n, g_opt.fov_y, g_opt.aspect, g_opt.zn, g_opt.zf,
+                                               d_send[b & 1], (uint64_t)part.max_mesh_tiles_per_rank * tile_bytes, d_bg[b & 1],
+                                               (uint64_t)part.n_bg_tiles * tile_bytes, (uint32_t)(b & 1));
+        if (rc != RR_OK) { fail(rc, "rr_render_orbit_mesh_sharded_lane"); break; }
         if ((rc = gather_pending()) != RR_OK) break;
-        pending_set = b & 1; pending_n = n;
+        pending_set = b & 1; pending_n = n; pending_part = part;
     }
     if (rc == RR_OK) rc = gather_pending();
     if (rc == RR_OK && g_rank == 0 && last_n > 0) {

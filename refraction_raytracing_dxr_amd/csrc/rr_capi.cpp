@@ -763,63 +763,10 @@ int ensure_lane(rr_context* ctx, uint32_t lane)
     return RR_OK;
 }
 
-// Screen rectangle (pixels, aligned outward to 8x8 blocks, 8 pixels of margin) that contains the projection of the box
-// {lo[3], hi[3]} for every one of the n slices' constants.  GenerateCameraRay (RayTracing.hlsl:27-40) sends pixel s to
-// the direction A * (sx, sy, 1) with A = columns 0, 1, 3 of proj_inv's upper three rows, so a point X is seen at
-// (a/c, b/c) where A * (a, b, c) = X - camera_loc, provided c > 0.
-// This rectangle is a CORRECTNESS path, not a hint: k_render_fused and k_render_paths do not trace the primary rays of
-// blocks outside it (their pixels are one Miss), and k_render_lds orders its work by it.  So it has to hold for the rays
-// the kernels really generate, which are fp32: R = (sx*M0 + sy*M1) + M3 per row carries an absolute error of a few
-// 2^-24 * (|M0| + |M1| + |M3|), i.e. the fp32 ray of pixel s is the exact ray of a pixel up to ||A^-1|| * that error away.
-// The 8-pixel margin (16 / max(W, H) in screen units, of which a quarter is spent here) therefore only covers matrices
-// whose condition number cond_inf(A) = ||A||_inf * ||A^-1||_inf stays below margin / 2^-20; anything worse -- a singular or
-// near-singular proj_inv, non-finite constants, a corner at or behind the camera plane (the camera inside or beside the
-// box), a projection that overflows -- makes the rectangle the whole frame, which is always right.
-// cams == nullptr (RR_DISPATCH_DEBUG_NO_CULL, and callers without a host copy of the constants): the whole frame.
-void mesh_screen_rect(const float box[6], const rr_scene_constants* cams, uint32_t n, uint32_t W, uint32_t H, uint32_t r[4])
+// (the screen rectangle of the scene bounds: rr_host_screen_rect, csrc/host/rr_host_partition.cpp)
+inline void mesh_screen_rect(const float box[6], const rr_scene_constants* cams, uint32_t n, uint32_t W, uint32_t H, uint32_t r[4])
 {
-    double x0 = 1e30, y0 = 1e30, x1 = -1e30, y1 = -1e30;
-    bool all = cams == nullptr;
-    for (int k = 0; k < 6 && !all; ++k) if (!std::isfinite(box[k])) all = true;
-    const double margin_s = 16.0 / (double)std::max(W, H);          // 8 pixels in screen units (the frame spans 2)
-    for (uint32_t f = 0; f < n && !all; ++f) {
-        const float* M = cams[f].proj_inv;
-        const double A[3][3] = { { M[0], M[1], M[3] }, { M[4], M[5], M[7] }, { M[8], M[9], M[11] } };
-        double norm_a = 0.0;
-        for (int i = 0; i < 3; ++i) norm_a = std::max(norm_a, std::fabs(A[i][0]) + std::fabs(A[i][1]) + std::fabs(A[i][2]));
-        for (int i = 0; i < 3; ++i) if (!std::isfinite(cams[f].camera_loc[i])) all = true;
-        if (all || !std::isfinite(norm_a) || !(norm_a > 0.0)) { all = true; break; }
-        // adjugate (cofactors transposed): A^-1 = adj / det
-        const double adj[3][3] = {
-            { A[1][1] * A[2][2] - A[1][2] * A[2][1], A[0][2] * A[2][1] - A[0][1] * A[2][2], A[0][1] * A[1][2] - A[0][2] * A[1][1] },
-            { A[1][2] * A[2][0] - A[1][0] * A[2][2], A[0][0] * A[2][2] - A[0][2] * A[2][0], A[0][2] * A[1][0] - A[0][0] * A[1][2] },
-            { A[1][0] * A[2][1] - A[1][1] * A[2][0], A[0][1] * A[2][0] - A[0][0] * A[2][1], A[0][0] * A[1][1] - A[0][1] * A[1][0] } };
-        const double det = A[0][0] * adj[0][0] + A[0][1] * adj[1][0] + A[0][2] * adj[2][0];
-        double norm_adj = 0.0;
-        for (int i = 0; i < 3; ++i) norm_adj = std::max(norm_adj, std::fabs(adj[i][0]) + std::fabs(adj[i][1]) + std::fabs(adj[i][2]));
-        // cond = norm_a * norm_adj / |det|; require cond * 2^-20 <= margin_s / 4 (written without the division)
-        if (!std::isfinite(det) || !std::isfinite(norm_adj) || !(std::fabs(det) * margin_s * 0.25 >= norm_a * norm_adj * 9.5367431640625e-07)) { all = true; break; }
-        for (int c = 0; c < 8 && !all; ++c) {
-            const double d[3] = { (double)((c & 1) ? box[3] : box[0]) - cams[f].camera_loc[0],
-                                  (double)((c & 2) ? box[4] : box[1]) - cams[f].camera_loc[1],
-                                  (double)((c & 4) ? box[5] : box[2]) - cams[f].camera_loc[2] };
-            const double a = (adj[0][0] * d[0] + adj[0][1] * d[1] + adj[0][2] * d[2]) / det;
-            const double b = (adj[1][0] * d[0] + adj[1][1] * d[1] + adj[1][2] * d[2]) / det;
-            const double cc = (adj[2][0] * d[0] + adj[2][1] * d[1] + adj[2][2] * d[2]) / det;
-            // in front of the camera plane by a margin relative to the corner's own size in these coordinates (a corner
-            // near the plane projects to infinity, and its sign is not to be trusted)
-            if (!(cc > 1e-4 * (std::fabs(a) + std::fabs(b) + std::fabs(cc))) || !(cc > 0.0)) { all = true; break; }
-            const double sx = a / cc, sy = b / cc;
-            const double px = (sx + 1.0) * 0.5 * W - 0.5, py = (1.0 - sy) * 0.5 * H - 0.5;
-            if (!(std::fabs(px) < 1e9 && std::fabs(py) < 1e9)) { all = true; break; }
-            x0 = std::min(x0, px); x1 = std::max(x1, px); y0 = std::min(y0, py); y1 = std::max(y1, py);
-        }
-    }
-    const uint32_t W8 = (W + 7u) & ~7u, H8 = (H + 7u) & ~7u;
-    if (all) { r[0] = 0; r[1] = 0; r[2] = W8; r[3] = H8; return; }
-    auto lo8 = [](double v, uint32_t lim) { const double q = std::floor((v - 8.0) / 8.0) * 8.0; return q <= 0.0 ? 0u : q >= lim ? lim : (uint32_t)q; };
-    auto hi8 = [](double v, uint32_t lim) { const double q = std::ceil((v + 9.0) / 8.0) * 8.0; return q <= 0.0 ? 0u : q >= lim ? lim : (uint32_t)q; };
-    r[0] = lo8(x0, W8); r[1] = lo8(y0, H8); r[2] = hi8(x1, W8); r[3] = hi8(y1, H8);
+    (void)rr_host_screen_rect(box, cams, n, W, H, r);
 }
 
 // ---- k_stream_* : buffers and passes ----------------------------------------------------------------------------------
@@ -909,13 +856,16 @@ int render_stream(rr_context* ctx, const SceneDev& sc, const DispatchDev& a, uin
     return RR_OK;
 }
 
+// mesh-tile partition (rr_mesh_partition): where rank 0's background tiles of a dispatch go
+struct MeshOut { uint32_t* bg; size_t bg_stride_elems; };
+
 inline bool timed_request(const rr_dispatch_params& p) { return (p.flags & RR_DISPATCH_TIME_KERNEL) != 0; }
 
 // out_slot: which of the frames_in_flight output regions of the internal frame buffer this dispatch writes;
 // h_cams: host copy of the depth slices' constants (may be null: no ordering hint)
 int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t depth, const CamDev* d_cams,
                   const rr_scene_constants* h_cams, const rr_dispatch_params& p, uint32_t* ext_tiles, size_t ext_stride_elems,
-                  bool keep_counters, uint32_t out_slot = 0, uint32_t out_slot_depth = 0)
+                  bool keep_counters, uint32_t out_slot = 0, uint32_t out_slot_depth = 0, const MeshOut* mesh = nullptr)
 {
     if (width == 0 || height == 0 || width > 32768 || height > 32768 || depth == 0 || depth > 65535)
         return fail(ctx, RR_ERR_INVALID_ARGUMENT, "dispatch: bad frame size or depth");
@@ -927,6 +877,18 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
 
     uint32_t tiles_x, n_tiles, local, max_local;
     tile_counts(width, height, ctx->tile_rank, ctx->tile_world, tiles_x, n_tiles, local, max_local);
+    rr_mesh_partition part;
+    memset(&part, 0, sizeof part);
+    uint32_t n_mesh_local = 0;
+    if (mesh) {         // mesh tiles dealt round robin, background tiles to rank 0: this rank's tiles are its mesh tiles, then those
+        if (!ext_tiles || !(p.flags & RR_DISPATCH_TILES_RGB8) || !h_cams) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "mesh partition: RGB8 tile buffers and host constants");
+        if (rr_host_mesh_partition(ctx->scene_bounds, (p.flags & RR_DISPATCH_DEBUG_NO_CULL) ? nullptr : h_cams, depth, width, height, ctx->tile_world, &part) != RR_OK)
+            return fail(ctx, RR_ERR_INVALID_ARGUMENT, "mesh partition");
+        n_mesh_local = part.n_mesh_tiles > ctx->tile_rank ? (part.n_mesh_tiles - ctx->tile_rank + ctx->tile_world - 1) / ctx->tile_world : 0;
+        if (ctx->tile_rank == 0 && part.n_bg_tiles && !mesh->bg) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "mesh partition: rank 0 needs the background tile buffer");
+        local = n_mesh_local + (ctx->tile_rank == 0 ? part.n_bg_tiles : 0);
+        max_local = part.max_mesh_tiles_per_rank;
+    }
     const bool want_f32 = (p.flags & RR_DISPATCH_FLOAT_OUTPUT) != 0;
     const bool compact = ctx->tile_world > 1 || ext_tiles != nullptr;
     const bool rgb8 = (p.flags & RR_DISPATCH_TILES_RGB8) != 0;
@@ -960,7 +922,15 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         mesh_screen_rect(ctx->scene_bounds, (p.flags & RR_DISPATCH_DEBUG_NO_CULL) ? nullptr : h_cams, depth, width, height, hr);
         a.hx0 = hr[0]; a.hy0 = hr[1]; a.hx1 = hr[2]; a.hy1 = hr[3];
     }
-    if (ctx->dbg_tile_order && ctx->tile_world == 1 && n_tiles < 65536u && a.hx1 > a.hx0 && a.hy1 > a.hy0) {
+    if (mesh) {
+        a.mesh_part = 1u; a.n_mesh_local = n_mesh_local; a.n_rect_tiles = part.n_mesh_tiles;
+        a.out_bg = mesh->bg; a.bg_stride = mesh->bg_stride_elems;
+        if (part.rect_w) {
+            a.rt_x0 = part.rect_x0; a.rt_y0 = part.rect_y0; a.rt_w = part.rect_w; a.rt_h = part.rect_h;
+            a.rt_div_w = (uint32_t)(0x100000000ull / a.rt_w) + 1u;
+            a.rt_div_o = tiles_x > a.rt_w ? (uint32_t)(0x100000000ull / (tiles_x - a.rt_w)) + 1u : 0u;
+        }
+    } else if (ctx->dbg_tile_order && ctx->tile_world == 1 && n_tiles < 65536u && a.hx1 > a.hx0 && a.hy1 > a.hy0) {
         // unsharded frames: the tiles that touch the rectangle are rendered first (DispatchDev::rt_*)
         const uint32_t tiles_y = (height + TILE - 1) / TILE;
         const uint32_t x0 = a.hx0 / TILE, y0 = a.hy0 / TILE;
@@ -1002,10 +972,11 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     const bool stats = (p.flags & RR_DISPATCH_COLLECT_STATS) != 0;
     const uint32_t need = scene_stack_need(ctx);
     const bool keep = keep_counters || (p.flags & RR_DISPATCH_KEEP_COUNTERS) != 0;
-    if (compact && local < max_local)            // keep the gathered tail deterministic
+    const uint32_t filled = mesh ? n_mesh_local : local;       // slots of the (gathered) tile buffer this rank writes
+    if (compact && filled < max_local)           // keep the gathered tail deterministic
         for (uint32_t f = 0; f < depth; ++f)
-            RR_HIP(hipMemsetAsync(reinterpret_cast<uint8_t*>(a.out_rgba8 + f * stride) + (size_t)local * TILE * TILE * (rgb8 ? 3 : 4), 0,
-                                  (size_t)(max_local - local) * TILE * TILE * (rgb8 ? 3 : 4), ctx->stream));
+            RR_HIP(hipMemsetAsync(reinterpret_cast<uint8_t*>(a.out_rgba8 + f * stride) + (size_t)filled * TILE * TILE * (rgb8 ? 3 : 4), 0,
+                                  (size_t)(max_local - filled) * TILE * TILE * (rgb8 ? 3 : 4), ctx->stream));
     int stack_sel = need <= 19 ? 19 : need <= 22 ? 22 : need <= 26 ? 26 : need <= 31 ? 31 : need <= 39 ? 39 : 64;     // rr_render.hip: sizes that fill the LDS with 6 / 5 / 4 / 2 workgroups
     if (ctx->dbg_stack >= (int)need) stack_sel = ctx->dbg_stack;   // experiments only; never below the tree depth (the kernels do not check)
     // the reference's scene with a node array small enough for LDS (its own meshes up to shell.obj): persistent workgroups,
@@ -1036,7 +1007,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     const bool refill_stack16 = ctx->single_identity ? (m0 && m0->n_tris < 32768u && need > 19)
                                                      : (pool_nodes < 32768u && ctx->n_pool_tris + ctx->n_insts < 32768u);
     // ---- the candidates
-    const bool stream_ok = !ctx->single_identity && p.max_reflect <= 2 && p.max_refract <= (int)STREAM_MAX_GEN - 2 && refill_stack16 && need <= 39 &&
+    const bool stream_ok = !mesh && !ctx->single_identity && p.max_reflect <= 2 && p.max_refract <= (int)STREAM_MAX_GEN - 2 && refill_stack16 && need <= 39 &&
                            !a.diag && ctx->dbg_stack == 0 && !ctx->dbg_tlas32;
     const bool paths_ok = !compact && ctx->tile_world == 1 && p.max_reflect <= 2 && need <= 39 && ctx->dbg_stack == 0 && have_rect && depth <= 2;
     auto launch_fused = [&](bool st) -> int {
@@ -1095,11 +1066,11 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     int cand_b = K_FUSED;
     if (ctx->dbg_kernel == 10) { if (stream_ok) kernel = K_STREAM; }
     else if (ctx->dbg_kernel == 5) { if (paths_ok) kernel = K_PATHS; }
-    else if (ctx->dbg_kernel == 4) { if (lds_fits) kernel = K_LDS; }
+    else if (ctx->dbg_kernel == 4) { if (lds_fits && !mesh) kernel = K_LDS; }
     else if (ctx->dbg_kernel == 0 && !a.diag) {
         if (stream_ok) { ch = &ctx->ch_tlas; cand_b = K_STREAM; }
         else if (paths_ok) { ch = &ctx->ch_few; cand_b = K_PATHS; }
-        else if (lds_fits && depth >= 3 && !compact) { ch = &ctx->ch_many; cand_b = K_LDS; }
+        else if (lds_fits && depth >= 3 && !compact && !mesh) { ch = &ctx->ch_many; cand_b = K_LDS; }
     }
     if (a.diag && paths_ok && rect_share < 0.25 && ctx->dbg_kernel == 0) kernel = K_PATHS;      // (the diagnostic builds keep round 2's rule)
     if (ch) {
@@ -1165,11 +1136,19 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     ctx->last_stats = stats;
     // pixels actually owned by this rank (partial edge tiles counted exactly)
     uint64_t px = 0;
-    for (uint32_t t = ctx->tile_rank; t < n_tiles; t += ctx->tile_world) {
-        uint32_t x0 = (t % tiles_x) * TILE, y0 = (t / tiles_x) * TILE;
-        uint32_t w = width - x0 < TILE ? width - x0 : TILE, h = height - y0 < TILE ? height - y0 : TILE;
-        px += (uint64_t)w * h;
-    }
+    auto tile_px = [&](uint32_t t) {
+        const uint32_t x0 = (t % tiles_x) * TILE, y0 = (t / tiles_x) * TILE;
+        const uint32_t w = width - x0 < TILE ? width - x0 : TILE, h = height - y0 < TILE ? height - y0 : TILE;
+        return (uint64_t)w * h;
+    };
+    if (!mesh) for (uint32_t t = ctx->tile_rank; t < n_tiles; t += ctx->tile_world) px += tile_px(t);
+    else
+        for (uint32_t t = 0; t < n_tiles; ++t) {
+            const uint32_t tx = t % tiles_x, ty = t / tiles_x;
+            const bool in_rect = part.rect_w == 0 || (tx >= part.rect_x0 && tx < part.rect_x0 + part.rect_w && ty >= part.rect_y0 && ty < part.rect_y0 + part.rect_h);
+            const uint32_t i = part.rect_w == 0 ? t : (ty - part.rect_y0) * part.rect_w + (tx - part.rect_x0);
+            if (in_rect ? i % ctx->tile_world == ctx->tile_rank : ctx->tile_rank == 0) px += tile_px(t);
+        }
     px *= depth;
     ctx->last_pixels = px;
     ctx->accum_pixels = (keep ? ctx->accum_pixels : 0) + px;
@@ -1438,6 +1417,98 @@ int rr_render_orbit_sharded_lane(rr_context* ctx, uint32_t width, uint32_t heigh
     if (rc != RR_OK) return rc;
     if (e != hipSuccess) return fail(ctx, RR_ERR_DEVICE, "rr_render_orbit_sharded_lane: event", e);
     ctx->lane_busy[lane] = true;
+    return RR_OK;
+}
+
+int rr_mesh_partition_for_orbit(rr_context* ctx, uint32_t width, uint32_t height, float angle, float angle_step, uint32_t n_frames,
+                                float fov_y, float aspect, float zn, float zf, rr_mesh_partition* out)
+{
+    if (!ctx || !out || n_frames == 0) return RR_ERR_INVALID_ARGUMENT;
+    if (!ctx->tlas_built) return fail(ctx, RR_ERR_STATE, "rr_mesh_partition_for_orbit: build the BLAS and TLAS first");
+    std::vector<rr_scene_constants> cams(n_frames);
+    for (uint32_t k = 0; k < n_frames; ++k) {
+        const int rc = rr_host_camera_orbit(angle, fov_y, aspect, zn, zf, &cams[k]);
+        if (rc != RR_OK) return fail(ctx, rc, "rr_mesh_partition_for_orbit: camera");
+        angle += angle_step;
+    }
+    return rr_host_mesh_partition(ctx->scene_bounds, cams.data(), n_frames, width, height, ctx->tile_world, out);
+}
+
+int rr_render_orbit_mesh_sharded_lane(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispatch_params* params, float* angle,
+                                      float angle_step, uint32_t n_frames, float fov_y, float aspect, float zn, float zf, void* d_mesh_tiles,
+                                      uint64_t mesh_stride_bytes, void* d_bg_tiles, uint64_t bg_stride_bytes, uint32_t lane)
+{
+    const Range range_("rr_render_orbit_mesh_sharded");
+    if (int r = use_device(ctx)) return r;
+    if (lane >= rr_context::MAX_LANES) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_render_orbit_mesh_sharded_lane: lane out of range");
+    if (!angle || !d_mesh_tiles || n_frames == 0 || (mesh_stride_bytes & 3u) || (bg_stride_bytes & 3u))
+        return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_render_orbit_mesh_sharded_lane: bad arguments");
+    if (int r = ensure_lane(ctx, lane)) return r;
+    rr_dispatch_params p;
+    if (params) p = *params; else rr_default_dispatch_params(&p);
+    p.flags |= RR_DISPATCH_TILES_RGB8;
+    std::vector<rr_scene_constants> cams(n_frames);
+    for (uint32_t k = 0; k < n_frames; ++k) {
+        const int rc = rr_host_camera_orbit(*angle, fov_y, aspect, zn, zf, &cams[k]);
+        if (rc != RR_OK) return fail(ctx, rc, "render_orbit: camera");
+        *angle += angle_step;
+    }
+    rr_mesh_partition part;
+    if (rr_host_mesh_partition(ctx->scene_bounds, cams.data(), n_frames, width, height, ctx->tile_world, &part) != RR_OK)
+        return fail(ctx, RR_ERR_INVALID_ARGUMENT, "mesh partition");
+    if (mesh_stride_bytes < (uint64_t)part.max_mesh_tiles_per_rank * TILE * TILE * 3 ||
+        (ctx->tile_rank == 0 && part.n_bg_tiles && (!d_bg_tiles || bg_stride_bytes < (uint64_t)part.n_bg_tiles * TILE * TILE * 3)))
+        return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_render_orbit_mesh_sharded_lane: tile buffers smaller than rr_mesh_partition_for_orbit says");
+    const bool keep = (p.flags & RR_DISPATCH_KEEP_COUNTERS) != 0;
+    if (!keep) {                                        // zero the counters where every lane will see it: before the fork
+        RR_HIP(hipMemsetAsync(ctx->d_cnt, 0, sizeof(CounterBlock), ctx->stream));
+        ctx->accum_pixels = 0;
+        p.flags |= RR_DISPATCH_KEEP_COUNTERS;
+    }
+    ctx->cam = cams.back(); ctx->cam_set = true;
+    RR_HIP(hipEventRecord(ctx->lane_fork[lane], ctx->stream));
+    RR_HIP(hipStreamWaitEvent(ctx->lane_stream[lane], ctx->lane_fork[lane], 0));
+    hipStream_t main_stream = ctx->stream;
+    CamDev* main_cams = ctx->d_cams;
+    size_t main_cap = ctx->cams_cap;
+    ctx->stream = ctx->lane_stream[lane];               // the lane has its own constant buffer: no reuse race between lanes
+    ctx->d_cams = ctx->lane_cams[lane];
+    ctx->cams_cap = ctx->lane_cams_cap[lane];
+    int rc = upload_cams(ctx, cams.data(), n_frames);
+    const MeshOut mo = { (uint32_t*)d_bg_tiles, (size_t)(bg_stride_bytes / 4) };
+    if (rc == RR_OK) rc = dispatch_impl(ctx, width, height, n_frames, ctx->d_cams, cams.data(), p, (uint32_t*)d_mesh_tiles, (size_t)(mesh_stride_bytes / 4), true, 0, 0, &mo);
+    hipError_t e = rc == RR_OK ? hipEventRecord(ctx->lane_done[lane], ctx->stream) : hipSuccess;
+    ctx->lane_cams[lane] = ctx->d_cams;
+    ctx->lane_cams_cap[lane] = ctx->cams_cap;
+    ctx->stream = main_stream;
+    ctx->d_cams = main_cams;
+    ctx->cams_cap = main_cap;
+    if (rc != RR_OK) return rc;
+    if (e != hipSuccess) return fail(ctx, RR_ERR_DEVICE, "rr_render_orbit_mesh_sharded_lane: event", e);
+    ctx->lane_busy[lane] = true;
+    return RR_OK;
+}
+
+int rr_assemble_frames_mesh_rgb8(rr_context* ctx, const void* d_gathered, uint64_t rank_stride_bytes, uint64_t frame_stride_bytes,
+                                 const void* d_bg_tiles, uint64_t bg_stride_bytes, const rr_mesh_partition* part, uint32_t n_frames,
+                                 uint32_t width, uint32_t height, void* d_frames, uint64_t out_stride_bytes)
+{
+    const Range range_("rr_assemble_frames_mesh_rgb8");
+    if (int r = use_device(ctx)) return r;
+    if (!d_gathered || !d_frames || !part || part->world == 0 || width == 0 || height == 0 ||
+        ((rank_stride_bytes | frame_stride_bytes | bg_stride_bytes | out_stride_bytes | (uint64_t)(uintptr_t)d_gathered | (uint64_t)(uintptr_t)d_bg_tiles) & 3u))
+        return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_assemble_frames_mesh_rgb8: bad arguments (strides and buffers are 4-byte aligned)");
+    const uint32_t tiles_x = (width + TILE - 1) / TILE, n_tiles = tiles_x * ((height + TILE - 1) / TILE);
+    if (part->tiles_x != tiles_x || part->n_tiles != n_tiles || part->n_mesh_tiles + part->n_bg_tiles != n_tiles ||
+        (part->rect_w == 0 ? part->n_bg_tiles != 0 : (part->rect_w * part->rect_h != part->n_mesh_tiles || part->rect_x0 + part->rect_w > tiles_x ||
+                                                      (part->rect_y0 + part->rect_h) * tiles_x > n_tiles)))
+        return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_assemble_frames_mesh_rgb8: the partition is not one of this frame size");
+    if (frame_stride_bytes < (uint64_t)part->max_mesh_tiles_per_rank * TILE * TILE * 3 || out_stride_bytes < (uint64_t)width * height * 4 ||
+        (part->n_bg_tiles && (!d_bg_tiles || bg_stride_bytes < (uint64_t)part->n_bg_tiles * TILE * TILE * 3)))
+        return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_assemble_frames_mesh_rgb8: stride too small");
+    const MeshPartDev mp = { part->tiles_x, part->n_tiles, part->rect_x0, part->rect_y0, part->rect_w, part->rect_h, part->world };
+    RR_HIP(launch_assemble_frames_mesh_rgb8((const uint8_t*)d_gathered, (const uint8_t*)d_bg_tiles, (uint32_t*)d_frames, width, height, mp, rank_stride_bytes,
+                                            frame_stride_bytes, bg_stride_bytes, out_stride_bytes / 4, n_frames, ctx->stream));
     return RR_OK;
 }
 

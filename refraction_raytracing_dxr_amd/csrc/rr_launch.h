@@ -20,6 +20,8 @@ int lds_kernel_shape(uint32_t node_bytes, uint32_t stack_entries, size_t* lds_by
 hipError_t launch_render_lds(const SceneDev& sc, const DispatchDev& a, LdsDispatch q, int n_cus, bool stats, hipStream_t s, int min_shape = 0);
 // launches of one or two slices: four lanes per pixel inside the scene's screen rectangle (k_render_paths)
 hipError_t launch_render_paths(const SceneDev& sc, const DispatchDev& a, int stack, bool stats, hipStream_t s);
+hipError_t launch_assemble_frames_mesh_rgb8(const uint8_t* gathered, const uint8_t* bg, uint32_t* frames, uint32_t W, uint32_t H, const MeshPartDev& mp,
+                                            size_t rank_stride_b, size_t frame_stride_b, size_t bg_stride_b, size_t out_stride, uint32_t n_frames, hipStream_t s);
 // ---- rr_render_stream.hip: one kernel per ray generation, rays in HBM queues, lanes refilled as their rays end (two-level scenes)
 hipError_t launch_render_stream(const SceneDev& sc, const DispatchDev& a, const StreamDev& s, int stack, uint32_t n_wg, bool stats, hipStream_t st, int waves = 6);
 const char* last_stream_kernel_name();

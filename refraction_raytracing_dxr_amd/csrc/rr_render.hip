@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256, WPS ? WPS : TLAS ? RR_TLAS_WAVES_PER_SIMD(STAC
     const uint32_t x = bp.x0 + lx, y = bp.y0 + ly;
     const bool valid = bp.tile_ok && x < a.W && y < a.H;
     const CamDev& cb = a.cams[bp.frame];                              // wave-uniform: scalar loads
-    uint32_t* const out_rgba8 = a.out_rgba8 + (size_t)bp.frame * a.frame_stride;
+    uint32_t* const out_rgba8 = bp.bg ? a.out_bg + (size_t)bp.frame * a.bg_stride : a.out_rgba8 + (size_t)bp.frame * a.frame_stride;
     float4* const out_f32 = a.out_f32 ? a.out_f32 + (size_t)bp.frame * a.frame_stride : nullptr;
 
     LaneStats st;
@@ -538,6 +538,63 @@ __global__ __launch_bounds__(256) void k_assemble_frames_rgb8(const uint8_t* __r
     }
 }
 
+
+// the mesh-tile partition's de-interleave (rr_mesh_partition): a tile inside the rectangle comes from the gathered buffer of the
+// rank it was dealt to, any other tile from rank 0's own background tiles.  RGB8 in, RGBA8 rasters out; one workgroup per tile
+// and frame, one thread per group of four pixels of a tile row.
+template <bool VEC4>
+__global__ __launch_bounds__(256) void k_assemble_frames_mesh_rgb8(const uint8_t* __restrict__ gathered, const uint8_t* __restrict__ bg,
+                                                                   uint32_t* __restrict__ frames, uint32_t W, uint32_t H, MeshPartDev mp,
+                                                                   size_t rank_stride_b, size_t frame_stride_b, size_t bg_stride_b, size_t out_stride)
+{
+    const uint32_t tile = blockIdx.x, f = blockIdx.y;
+    if (tile >= mp.n_tiles) return;
+    const uint32_t tx = tile % mp.tiles_x, ty = tile / mp.tiles_x;
+    const uint8_t* src;
+    if (mp.rect_w == 0u) {
+        src = gathered + (size_t)(tile % mp.world) * rank_stride_b + f * frame_stride_b + (size_t)(tile / mp.world) * (TILE * TILE * 3);
+    } else if (tx >= mp.rect_x0 && tx < mp.rect_x0 + mp.rect_w && ty >= mp.rect_y0 && ty < mp.rect_y0 + mp.rect_h) {
+        const uint32_t i = (ty - mp.rect_y0) * mp.rect_w + (tx - mp.rect_x0);
+        src = gathered + (size_t)(i % mp.world) * rank_stride_b + f * frame_stride_b + (size_t)(i / mp.world) * (TILE * TILE * 3);
+    } else {
+        const uint32_t per_row = mp.tiles_x - mp.rect_w;
+        uint32_t j;
+        if (ty < mp.rect_y0) j = ty * mp.tiles_x + tx;
+        else if (ty < mp.rect_y0 + mp.rect_h) j = mp.rect_y0 * mp.tiles_x + (ty - mp.rect_y0) * per_row + (tx < mp.rect_x0 ? tx : tx - mp.rect_w);
+        else j = mp.rect_y0 * mp.tiles_x + mp.rect_h * per_row + (ty - mp.rect_y0 - mp.rect_h) * mp.tiles_x + tx;
+        src = bg + f * bg_stride_b + (size_t)j * (TILE * TILE * 3);
+    }
+    const uint32_t py = threadIdx.x >> 3, px = (threadIdx.x & 7u) * 4u;
+    const uint32_t x = tx * TILE + px, y = ty * TILE + py;
+    if (y >= H || x >= W) return;
+    const uint32_t* p4 = reinterpret_cast<const uint32_t*>(src + (py * TILE + px) * 3);
+    const uint32_t w0 = p4[0], w1 = p4[1], w2 = p4[2];
+    uint4 o;
+    o.x = (w0 & 0x00ffffffu) | 0xff000000u;
+    o.y = (((w0 >> 24) | (w1 << 8)) & 0x00ffffffu) | 0xff000000u;
+    o.z = (((w1 >> 16) | (w2 << 16)) & 0x00ffffffu) | 0xff000000u;
+    o.w = (w2 >> 8) | 0xff000000u;
+    uint32_t* dst = frames + f * out_stride + (size_t)y * W + x;
+    if (VEC4) *reinterpret_cast<uint4*>(dst) = o;
+    else {
+        dst[0] = o.x;
+        if (x + 1 < W) dst[1] = o.y;
+        if (x + 2 < W) dst[2] = o.z;
+        if (x + 3 < W) dst[3] = o.w;
+    }
+}
+
+hipError_t launch_assemble_frames_mesh_rgb8(const uint8_t* gathered, const uint8_t* bg, uint32_t* frames, uint32_t W, uint32_t H, const MeshPartDev& mp,
+                                            size_t rank_stride_b, size_t frame_stride_b, size_t bg_stride_b, size_t out_stride, uint32_t n_frames, hipStream_t s)
+{
+    if (mp.n_tiles == 0 || n_frames == 0) return hipSuccess;
+    const bool vec4 = (W % 4u) == 0u && (out_stride % 4u) == 0u && (reinterpret_cast<uintptr_t>(frames) % 16u) == 0u;
+    if (vec4) hipLaunchKernelGGL(k_assemble_frames_mesh_rgb8<true>, dim3(mp.n_tiles, n_frames), dim3(256), 0, s, gathered, bg, frames, W, H, mp,
+                                 rank_stride_b, frame_stride_b, bg_stride_b, out_stride);
+    else      hipLaunchKernelGGL(k_assemble_frames_mesh_rgb8<false>, dim3(mp.n_tiles, n_frames), dim3(256), 0, s, gathered, bg, frames, W, H, mp,
+                                 rank_stride_b, frame_stride_b, bg_stride_b, out_stride);
+    return hipGetLastError();
+}
 
 // ------------------------------------------------------------------------------------ launchers
 // name of the render kernel instantiation the calling thread launched last (rr_stats::render_kernel_name)

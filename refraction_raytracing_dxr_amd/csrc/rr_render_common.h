@@ -260,9 +260,9 @@ __device__ __forceinline__ void flush_stats(const DispatchDev& a, const LaneStat
 // depth slices are interleaved: mixing the slices keeps every CU on a blend of cheap background waves and expensive mesh
 // waves -- monkey.obj 1080p, Depth 16: 193 us/frame interleaved, 238 us slice after slice).
 // i-th tile of a launch in the order "rectangle first" (DispatchDev::rt_*): everything is wave-uniform scalar arithmetic
-__device__ __forceinline__ uint32_t tile_in_launch_order(const DispatchDev& a, uint32_t i)
+__device__ __forceinline__ uint32_t tile_in_launch_order(const DispatchDev& a, uint32_t i, uint32_t limit)
 {
-    if (a.rt_w == 0u || i >= a.n_local_tiles) return i;
+    if (a.rt_w == 0u || i >= limit) return i;
     const uint32_t n_rect = a.rt_w * a.rt_h;
     if (i < n_rect) {
         const uint32_t row = a.rt_w == 1u ? i : __umulhi(i, a.rt_div_w);
@@ -280,7 +280,7 @@ __device__ __forceinline__ uint32_t tile_in_launch_order(const DispatchDev& a, u
     return (a.rt_y0 + a.rt_h) * a.tiles_x + (j - beside);
 }
 
-struct BlockPos { uint32_t frame, tile_local, x0, y0, px0, py0; bool tile_ok; };
+struct BlockPos { uint32_t frame, tile_local, x0, y0, px0, py0; bool tile_ok, bg; };
 __device__ __forceinline__ BlockPos wave_block_pos(const DispatchDev& a, uint32_t wb)
 {
     BlockPos p;
@@ -289,8 +289,18 @@ __device__ __forceinline__ BlockPos wave_block_pos(const DispatchDev& a, uint32_
     uint32_t strip;
     block_to_tile(blk / a.n_frames, p.tile_local, strip);
     p.tile_ok = p.tile_local < a.n_local_tiles;
-    p.tile_local = tile_in_launch_order(a, p.tile_local);
-    const uint32_t tile = p.tile_local * a.tile_world + a.tile_rank;
+    p.bg = false;
+    uint32_t tile;
+    if (a.mesh_part) {          // the rank's mesh tiles, then (rank 0) the background tiles: rr_mesh_partition
+        const uint32_t k = p.tile_local;
+        p.bg = k >= a.n_mesh_local;
+        const uint32_t i = p.bg ? a.n_rect_tiles + (k - a.n_mesh_local) : k * a.tile_world + a.tile_rank;
+        tile = tile_in_launch_order(a, i < a.n_tiles ? i : 0u, a.n_tiles);
+        p.tile_local = p.bg ? k - a.n_mesh_local : k;
+    } else {
+        p.tile_local = tile_in_launch_order(a, p.tile_local, a.n_local_tiles);
+        tile = p.tile_local * a.tile_world + a.tile_rank;
+    }
     const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     p.px0 = wave * 8u; p.py0 = strip * 8u;                         // inside the 32x32 tile
     p.x0 = tx * TILE + p.px0; p.y0 = ty * TILE + p.py0;

@@ -124,6 +124,12 @@ struct DispatchDev {
     // the last mesh waves (hundreds).  rt_w == 0: image order.  Tile units; rt_div_w / rt_div_o: 2^32 / d + 1 for the two
     // divisions (exact below 65 536 tiles).
     uint32_t rt_x0, rt_y0, rt_w, rt_h, rt_div_w, rt_div_o;
+    // mesh-tile partition (rr_mesh_partition): this rank's launch order is its n_mesh_local mesh tiles (order index k * world +
+    // rank among the rectangle's tiles), then -- rank 0 only -- every background tile; mesh tiles are written to out_rgba8
+    // (slot k), background tiles to out_bg (slot k - n_mesh_local)
+    uint32_t mesh_part, n_mesh_local, n_rect_tiles;
+    uint32_t* out_bg;
+    size_t   bg_stride;
     uint32_t group_trace;           // k_render_paths: 1 = ray levels with few rays left are traced by groups of 2 / 4 lanes per ray (trace_blas_group)
     uint32_t async_leaf_num, async_shade_num;   // k_stream_rays: lanes (in sixteenths of the live lanes) a step / a shading pass needs to be issued
     uint32_t* out_rgba8;            // world==1: W*H raster; else compact tiles
@@ -169,6 +175,9 @@ struct LdsDispatch {
 // therefore renders the launches of few slices).  RR_DEBUG_TICKET +64 / +128 select 64 / 512 queues for experiments.
 constexpr uint32_t LDS_QUEUES = 512;
 constexpr uint32_t LDS_TICKET_WORDS = (2 * LDS_QUEUES + 1) * 16;
+
+// rr_mesh_partition as the de-interleave kernel takes it
+struct MeshPartDev { uint32_t tiles_x, n_tiles, rect_x0, rect_y0, rect_w, rect_h, world; };
 
 // k_stream_* (rr_render_stream.hip): the ray queues of one pass of the generation-per-kernel renderer
 constexpr uint32_t STREAM_MAX_GEN = 64;     // head counters: generations 0 .. max_refract + 1 <= 63

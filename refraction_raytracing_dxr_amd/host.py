@@ -268,6 +268,31 @@ class Renderer:
         self.width, self.height = width, height
         return a.value
 
+    def mesh_partition_for_orbit(self, width, height, n_frames, angle=0.01, angle_step=0.01, fov_y=FOV_Y, aspect=ASPECT, zn=1.0, zf=125.0):
+        """rr_mesh_partition of the n_frames frames starting at `angle` for this context's (rank, world)."""
+        part = _capi.MeshPartition()
+        self._ck(self._L.rr_mesh_partition_for_orbit(self._h, width, height, float(np.float32(angle)), float(np.float32(angle_step)), n_frames,
+                                                     fov_y, aspect, zn, zf, C.byref(part)), "rr_mesh_partition_for_orbit")
+        return part
+
+    def render_orbit_mesh_sharded(self, width, height, n_frames, mesh_ptr, mesh_stride_bytes, bg_ptr, bg_stride_bytes, angle=0.01,
+                                  angle_step=0.01, params=None, lane=0, fov_y=FOV_Y, aspect=ASPECT, zn=1.0, zf=125.0):
+        """One DispatchRays(W, H, n_frames) of a sharded context under the mesh-tile partition, on render lane `lane`:
+        this rank's mesh tiles (RGB8) to mesh_ptr, rank 0's background tiles to bg_ptr.  -> the angle after the last frame."""
+        a = C.c_float(np.float32(angle))
+        p = params if params is not None else default_params()
+        self._ck(self._L.rr_render_orbit_mesh_sharded_lane(self._h, width, height, C.byref(p), C.byref(a), float(np.float32(angle_step)), n_frames,
+                                                           fov_y, aspect, zn, zf, mesh_ptr, mesh_stride_bytes, bg_ptr, bg_stride_bytes, lane),
+                 "rr_render_orbit_mesh_sharded_lane")
+        self.width, self.height = width, height
+        return float(a.value)
+
+    def assemble_frames_mesh(self, gathered_ptr, rank_stride_bytes, frame_stride_bytes, bg_ptr, bg_stride_bytes, part, n_frames, width, height,
+                             frames_ptr, out_stride_bytes):
+        self._ck(self._L.rr_assemble_frames_mesh_rgb8(self._h, gathered_ptr, rank_stride_bytes, frame_stride_bytes, bg_ptr, bg_stride_bytes,
+                                                      C.byref(part), n_frames, width, height, frames_ptr, out_stride_bytes),
+                 "rr_assemble_frames_mesh_rgb8")
+
     def set_frames_in_flight(self, n):
         """launches of render_orbit that may overlap (1 = the reference's one-at-a-time frame loop)"""
         self._ck(self._L.rr_set_frames_in_flight(self._h, n), "rr_set_frames_in_flight")

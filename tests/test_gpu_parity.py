@@ -1003,7 +1003,7 @@ def test_orbit_streamed_to_host_equals_draw_frame_sequence(gpu):
 
 
 # ------------------------------------------------------------------------------- N > 1 pipeline
-def _sharded_worker(rank, world, port, backend, out, rgb8=True, W=250):
+def _sharded_worker(rank, world, port, backend, out, rgb8=True, W=250, mesh=False):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -1018,7 +1018,7 @@ def _sharded_worker(rank, world, port, backend, out, rgb8=True, W=250):
     H, K, F = 130, 13, 2                           # 7 batches: every buffer set and both lanes are reused
     # world 1 under nccl: still issue the RCCL gather (async_op, views of the ring buffers), as the N > 1 ranks do
     sf = rr.dist.ShardedFrames(r, W, H, rank, world, torch.device("cuda", 0), frames_per_gather=F, rgb8=rgb8,
-                               always_collective=(backend == "nccl"))
+                               always_collective=(backend == "nccl"), mesh_partition=mesh)
     seen = []
     rays = sf.render_orbit(K, angle=0.01, params=rr.default_params(max_refract=8),
                            on_frames=(lambda fr: seen.append(fr.clone())) if rank == 0 else None)
@@ -1047,11 +1047,14 @@ def _sharded_worker(rank, world, port, backend, out, rgb8=True, W=250):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,backend,rgb8,W", [(1, "nccl", True, 250), (2, "gloo", True, 256), (2, "gloo", False, 250)])
-def test_sharded_frames_pipeline(tmp_path, world, backend, rgb8, W):
+@pytest.mark.parametrize("world,backend,rgb8,W,mesh", [(1, "nccl", True, 250, False), (2, "gloo", True, 256, False), (2, "gloo", False, 250, False),
+                                                       (1, "nccl", True, 256, True), (2, "gloo", True, 250, True), (3, "gloo", True, 256, True)])
+def test_sharded_frames_pipeline(tmp_path, world, backend, rgb8, W, mesh):
     """render -> (RCCL | gloo-staged) gather of F frames -> rr_assemble_frames[_rgb8], pipelined over batches,
-    equals frame-by-frame single-GPU rendering.  world 2 runs two processes on the one card; tiles travel as
-    RGB8 (the default; W = 256 takes the 16-byte-store path of the de-interleave, W = 250 the ragged one) or RGBA8."""
+    equals frame-by-frame single-GPU rendering.  world 2 / 3 run that many processes on the one card; tiles travel as
+    RGB8 (the default; W = 256 takes the 16-byte-store path of the de-interleave, W = 250 the ragged one) or RGBA8.
+    mesh: the mesh-tile partition (rr_mesh_partition) -- only the tiles that touch the scene's screen rectangle are dealt
+    and gathered, rank 0 renders the background tiles itself; the rectangle moves from batch to batch with the orbit."""
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as sk:
@@ -1059,7 +1062,7 @@ def test_sharded_frames_pipeline(tmp_path, world, backend, rgb8, W):
         port = sk.getsockname()[1]
     out = str(tmp_path / "ok.npy")
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, backend, out, rgb8, W)) for r in range(world)]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, backend, out, rgb8, W, mesh)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
