@@ -261,6 +261,11 @@ typedef struct rr_mesh_partition {
     uint32_t tiles_x, n_tiles;
     uint32_t rect_x0, rect_y0, rect_w, rect_h;      /* in tiles */
     uint32_t n_mesh_tiles, n_bg_tiles, max_mesh_tiles_per_rank, world;
+    uint32_t rank0_rounds;      /* how the mesh tiles are dealt: rank 0 also renders every background tile, so it takes fewer of them --
+                                   ranks 1 .. world-1 take one tile each for rank0_rounds rounds, then rank 0 takes one
+                                   (cycle of rank0_rounds * (world - 1) + 1 tiles); 0: plain round robin over all ranks (world == 1,
+                                   or no background); 0xffffffff: rank 0 takes none (the background alone is its share) */
+    uint32_t pad;
 } rr_mesh_partition;
 /* The mesh-tile partition for a sharded context, one DispatchRays(W, H, n_frames) per call:
  * rr_mesh_partition_for_orbit says how the n_frames frames starting at `angle` will be dealt (the rectangle is the union over
@@ -356,11 +361,16 @@ void rr_default_dispatch_params(rr_dispatch_params* p);
 int  rr_host_screen_rect(const float bounds[6], const rr_scene_constants* constants, uint32_t n, uint32_t width, uint32_t height,
                          uint32_t rect[4]);
 /* Multi-GPU tile partition that only moves what has to move: the tiles that touch the rectangle ("mesh tiles", raster order
- * inside the rectangle, index i) belong to rank i % world, slot i / world of that rank's tile buffer; all the other tiles
+ * inside the rectangle, index i) are dealt to the ranks in turn (rank0_rounds: rank 0 takes fewer, see the struct), each rank's
+ * tiles filling the slots of its tile buffer in order; all the other tiles
  * ("background tiles": one Miss per pixel, a tenth of the work and two thirds of the bytes of the reference's views) belong to
  * rank 0, in raster order, and never cross a link.  rect_w == 0: no usable rectangle, every tile is a mesh tile. */
 int  rr_host_mesh_partition(const float bounds[6], const rr_scene_constants* constants, uint32_t n, uint32_t width, uint32_t height,
                             uint32_t world, rr_mesh_partition* out);
+/* mesh tile `mesh_index` (raster order inside the rectangle) -> the rank it is dealt to and its slot in that rank's buffer;
+ * the number of mesh tiles a rank holds */
+int  rr_host_mesh_tile_home(const rr_mesh_partition* part, uint32_t mesh_index, uint32_t* rank, uint32_t* slot);
+uint32_t rr_host_mesh_tiles_of_rank(const rr_mesh_partition* part, uint32_t rank);
 /* RefractionDemo.cpp:559-566: camera constants for an orbit angle.  The reference's literals are
  * fov_y = float(52.0/180.0*3.1415), aspect = 1.333f, zn = 1, zf = 125; frame k uses angle 0.01*(k+1). */
 int  rr_host_camera_orbit(float angle, float fov_y, float aspect, float zn, float zf,

@@ -72,7 +72,7 @@ class MeshPartition(C.Structure):
     """rr_mesh_partition: mesh tiles dealt round robin, background tiles to rank 0"""
     _fields_ = [("tiles_x", C.c_uint32), ("n_tiles", C.c_uint32), ("rect_x0", C.c_uint32), ("rect_y0", C.c_uint32),
                 ("rect_w", C.c_uint32), ("rect_h", C.c_uint32), ("n_mesh_tiles", C.c_uint32), ("n_bg_tiles", C.c_uint32),
-                ("max_mesh_tiles_per_rank", C.c_uint32), ("world", C.c_uint32)]
+                ("max_mesh_tiles_per_rank", C.c_uint32), ("world", C.c_uint32), ("rank0_rounds", C.c_uint32), ("pad", C.c_uint32)]
 
 
 # every symbol include/rrdxr.h declares: name -> (restype, argtypes)
@@ -142,6 +142,8 @@ SYMBOLS = {
     "rr_default_dispatch_params": (None, [C.POINTER(DispatchParams)]),
     "rr_host_camera_orbit": (C.c_int, [C.c_float] * 5 + [C.POINTER(SceneConstants)]),
     "rr_host_screen_rect": (C.c_int, [C.POINTER(C.c_float), C.POINTER(SceneConstants), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "rr_host_mesh_tile_home": (C.c_int, [C.POINTER(MeshPartition), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "rr_host_mesh_tiles_of_rank": (C.c_uint32, [C.POINTER(MeshPartition), C.c_uint32]),
     "rr_host_mesh_partition": (C.c_int, [C.POINTER(C.c_float), C.POINTER(SceneConstants), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.POINTER(MeshPartition)]),
     "rr_host_mesh_load_obj": (C.c_int, [C.c_char_p, C.POINTER(_P), C.POINTER(C.c_uint32), C.POINTER(_P),

@@ -70,7 +70,37 @@ static void screen_rect(const float box[6], const rr_scene_constants* cams, uint
 
 } // namespace
 
+// ---- how mesh tile i of a partition is dealt (shared with the kernels through rr_types.h's MeshDeal: the same arithmetic) ----
+static void mesh_owner(uint32_t i, uint32_t world, uint32_t j, uint32_t& rank, uint32_t& slot)
+{
+    if (j == 0u || world == 1u) { rank = i % world; slot = i / world; return; }
+    if (j == 0xffffffffu) { rank = 1u + i % (world - 1u); slot = i / (world - 1u); return; }
+    const uint32_t cl = j * (world - 1u) + 1u, c = i / cl, pos = i % cl;
+    if (pos == cl - 1u) { rank = 0u; slot = c; }
+    else { rank = 1u + pos % (world - 1u); slot = c * j + pos / (world - 1u); }
+}
+
 extern "C" {
+
+uint32_t rr_host_mesh_tiles_of_rank(const rr_mesh_partition* part, uint32_t rank)
+{
+    if (!part || part->world == 0 || rank >= part->world) return 0;
+    const uint32_t n = part->n_mesh_tiles, w = part->world, j = part->rank0_rounds;
+    if (j == 0u || w == 1u) return n > rank ? (n - rank + w - 1u) / w : 0u;
+    if (j == 0xffffffffu) return rank == 0u ? 0u : (n > rank - 1u ? (n - (rank - 1u) + (w - 1u) - 1u) / (w - 1u) : 0u);
+    const uint32_t cl = j * (w - 1u) + 1u, full = n / cl, rem = n % cl;
+    if (rank == 0u) return full;                                            // (the cycle's last tile: a partial cycle never reaches it)
+    uint32_t c = full * j;
+    for (uint32_t pos = 0; pos < rem; ++pos) if (1u + pos % (w - 1u) == rank) ++c;
+    return c;
+}
+
+int rr_host_mesh_tile_home(const rr_mesh_partition* part, uint32_t mesh_index, uint32_t* rank, uint32_t* slot)
+{
+    if (!part || !rank || !slot || part->world == 0 || mesh_index >= part->n_mesh_tiles) return RR_ERR_INVALID_ARGUMENT;
+    mesh_owner(mesh_index, part->world, part->rank0_rounds, *rank, *slot);
+    return RR_OK;
+}
 
 int rr_host_screen_rect(const float bounds[6], const rr_scene_constants* constants, uint32_t n, uint32_t width, uint32_t height, uint32_t rect[4])
 {
@@ -103,7 +133,26 @@ int rr_host_mesh_partition(const float bounds[6], const rr_scene_constants* cons
         out->n_mesh_tiles = out->n_tiles;           // no rectangle (rect_w == 0): every tile is a mesh tile, in raster order
     }
     out->n_bg_tiles = out->n_tiles - out->n_mesh_tiles;
-    out->max_mesh_tiles_per_rank = (out->n_mesh_tiles + world - 1) / world;
+    // Rank 0 renders every background tile: it takes fewer mesh tiles, so that its share of the WORK is the others'.  A mesh tile
+    // is priced at 16 background tiles (the headline view's issue time: 74 % in 572 mesh tiles, 10 % in 1 468 background tiles).
+    out->rank0_rounds = 0;
+    if (world > 1 && out->n_bg_tiles > 0) {
+        const double cm = 16.0, total = (double)out->n_bg_tiles + cm * out->n_mesh_tiles, share = total / world;
+        const double m0 = (share - (double)out->n_bg_tiles) / cm;           // mesh tiles rank 0 should take
+        if (m0 < 0.5) out->rank0_rounds = 0xffffffffu;
+        else {
+            const double f0 = m0 / (double)out->n_mesh_tiles;               // its fraction of them: 1 / (J * (world - 1) + 1)
+            const double j = (1.0 / f0 - 1.0) / (double)(world - 1);
+            out->rank0_rounds = j < 1.0 ? 1u : j > 1.0e6 ? 0xffffffffu : (uint32_t)(j + 0.5);
+        }
+    }
+    uint32_t mx = 0;
+    {   // slots per rank (dense by construction): the largest count is what every rank's gather buffer holds per frame
+        uint32_t cnt_max = 0;
+        for (uint32_t r = 0; r < world; ++r) cnt_max = std::max(cnt_max, rr_host_mesh_tiles_of_rank(out, r));
+        mx = cnt_max;
+    }
+    out->max_mesh_tiles_per_rank = mx;
     return RR_OK;
 }
 

@@ -884,7 +884,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         if (!ext_tiles || !(p.flags & RR_DISPATCH_TILES_RGB8) || !h_cams) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "mesh partition: RGB8 tile buffers and host constants");
         if (rr_host_mesh_partition(ctx->scene_bounds, (p.flags & RR_DISPATCH_DEBUG_NO_CULL) ? nullptr : h_cams, depth, width, height, ctx->tile_world, &part) != RR_OK)
             return fail(ctx, RR_ERR_INVALID_ARGUMENT, "mesh partition");
-        n_mesh_local = part.n_mesh_tiles > ctx->tile_rank ? (part.n_mesh_tiles - ctx->tile_rank + ctx->tile_world - 1) / ctx->tile_world : 0;
+        n_mesh_local = rr_host_mesh_tiles_of_rank(&part, ctx->tile_rank);
         if (ctx->tile_rank == 0 && part.n_bg_tiles && !mesh->bg) return fail(ctx, RR_ERR_INVALID_ARGUMENT, "mesh partition: rank 0 needs the background tile buffer");
         local = n_mesh_local + (ctx->tile_rank == 0 ? part.n_bg_tiles : 0);
         max_local = part.max_mesh_tiles_per_rank;
@@ -923,7 +923,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         a.hx0 = hr[0]; a.hy0 = hr[1]; a.hx1 = hr[2]; a.hy1 = hr[3];
     }
     if (mesh) {
-        a.mesh_part = 1u; a.n_mesh_local = n_mesh_local; a.n_rect_tiles = part.n_mesh_tiles;
+        a.mesh_part = 1u; a.n_mesh_local = n_mesh_local; a.n_rect_tiles = part.n_mesh_tiles; a.mesh_rounds = part.rank0_rounds;
         a.out_bg = mesh->bg; a.bg_stride = mesh->bg_stride_elems;
         if (part.rect_w) {
             a.rt_x0 = part.rect_x0; a.rt_y0 = part.rect_y0; a.rt_w = part.rect_w; a.rt_h = part.rect_h;
@@ -1147,7 +1147,9 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
             const uint32_t tx = t % tiles_x, ty = t / tiles_x;
             const bool in_rect = part.rect_w == 0 || (tx >= part.rect_x0 && tx < part.rect_x0 + part.rect_w && ty >= part.rect_y0 && ty < part.rect_y0 + part.rect_h);
             const uint32_t i = part.rect_w == 0 ? t : (ty - part.rect_y0) * part.rect_w + (tx - part.rect_x0);
-            if (in_rect ? i % ctx->tile_world == ctx->tile_rank : ctx->tile_rank == 0) px += tile_px(t);
+            uint32_t owner = 0, slot = 0;
+            if (in_rect) (void)rr_host_mesh_tile_home(&part, i, &owner, &slot);
+            if (in_rect ? owner == ctx->tile_rank : ctx->tile_rank == 0) px += tile_px(t);
         }
     px *= depth;
     ctx->last_pixels = px;
@@ -1506,7 +1508,7 @@ int rr_assemble_frames_mesh_rgb8(rr_context* ctx, const void* d_gathered, uint64
     if (frame_stride_bytes < (uint64_t)part->max_mesh_tiles_per_rank * TILE * TILE * 3 || out_stride_bytes < (uint64_t)width * height * 4 ||
         (part->n_bg_tiles && (!d_bg_tiles || bg_stride_bytes < (uint64_t)part->n_bg_tiles * TILE * TILE * 3)))
         return fail(ctx, RR_ERR_INVALID_ARGUMENT, "rr_assemble_frames_mesh_rgb8: stride too small");
-    const MeshPartDev mp = { part->tiles_x, part->n_tiles, part->rect_x0, part->rect_y0, part->rect_w, part->rect_h, part->world };
+    const MeshPartDev mp = { part->tiles_x, part->n_tiles, part->rect_x0, part->rect_y0, part->rect_w, part->rect_h, part->world, part->rank0_rounds };
     RR_HIP(launch_assemble_frames_mesh_rgb8((const uint8_t*)d_gathered, (const uint8_t*)d_bg_tiles, (uint32_t*)d_frames, width, height, mp, rank_stride_bytes,
                                             frame_stride_bytes, bg_stride_bytes, out_stride_bytes / 4, n_frames, ctx->stream));
     return RR_OK;

@@ -551,11 +551,11 @@ __global__ __launch_bounds__(256) void k_assemble_frames_mesh_rgb8(const uint8_t
     if (tile >= mp.n_tiles) return;
     const uint32_t tx = tile % mp.tiles_x, ty = tile / mp.tiles_x;
     const uint8_t* src;
-    if (mp.rect_w == 0u) {
-        src = gathered + (size_t)(tile % mp.world) * rank_stride_b + f * frame_stride_b + (size_t)(tile / mp.world) * (TILE * TILE * 3);
-    } else if (tx >= mp.rect_x0 && tx < mp.rect_x0 + mp.rect_w && ty >= mp.rect_y0 && ty < mp.rect_y0 + mp.rect_h) {
-        const uint32_t i = (ty - mp.rect_y0) * mp.rect_w + (tx - mp.rect_x0);
-        src = gathered + (size_t)(i % mp.world) * rank_stride_b + f * frame_stride_b + (size_t)(i / mp.world) * (TILE * TILE * 3);
+    if (mp.rect_w == 0u || (tx >= mp.rect_x0 && tx < mp.rect_x0 + mp.rect_w && ty >= mp.rect_y0 && ty < mp.rect_y0 + mp.rect_h)) {
+        const uint32_t i = mp.rect_w == 0u ? tile : (ty - mp.rect_y0) * mp.rect_w + (tx - mp.rect_x0);
+        uint32_t rank, slot;
+        mesh_deal_owner(i, mp.world, mp.rounds, rank, slot);
+        src = gathered + (size_t)rank * rank_stride_b + f * frame_stride_b + (size_t)slot * (TILE * TILE * 3);
     } else {
         const uint32_t per_row = mp.tiles_x - mp.rect_w;
         uint32_t j;

@@ -294,7 +294,7 @@ __device__ __forceinline__ BlockPos wave_block_pos(const DispatchDev& a, uint32_
     if (a.mesh_part) {          // the rank's mesh tiles, then (rank 0) the background tiles: rr_mesh_partition
         const uint32_t k = p.tile_local;
         p.bg = k >= a.n_mesh_local;
-        const uint32_t i = p.bg ? a.n_rect_tiles + (k - a.n_mesh_local) : k * a.tile_world + a.tile_rank;
+        const uint32_t i = p.bg ? a.n_rect_tiles + (k - a.n_mesh_local) : mesh_deal_index(a.tile_rank, k, a.tile_world, a.mesh_rounds);
         tile = tile_in_launch_order(a, i < a.n_tiles ? i : 0u, a.n_tiles);
         p.tile_local = p.bg ? k - a.n_mesh_local : k;
     } else {

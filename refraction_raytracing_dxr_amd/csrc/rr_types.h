@@ -127,7 +127,7 @@ struct DispatchDev {
     // mesh-tile partition (rr_mesh_partition): this rank's launch order is its n_mesh_local mesh tiles (order index k * world +
     // rank among the rectangle's tiles), then -- rank 0 only -- every background tile; mesh tiles are written to out_rgba8
     // (slot k), background tiles to out_bg (slot k - n_mesh_local)
-    uint32_t mesh_part, n_mesh_local, n_rect_tiles;
+    uint32_t mesh_part, n_mesh_local, n_rect_tiles, mesh_rounds;     // mesh_rounds: rr_mesh_partition::rank0_rounds
     uint32_t* out_bg;
     size_t   bg_stride;
     uint32_t group_trace;           // k_render_paths: 1 = ray levels with few rays left are traced by groups of 2 / 4 lanes per ray (trace_blas_group)
@@ -177,7 +177,27 @@ constexpr uint32_t LDS_QUEUES = 512;
 constexpr uint32_t LDS_TICKET_WORDS = (2 * LDS_QUEUES + 1) * 16;
 
 // rr_mesh_partition as the de-interleave kernel takes it
-struct MeshPartDev { uint32_t tiles_x, n_tiles, rect_x0, rect_y0, rect_w, rect_h, world; };
+struct MeshPartDev { uint32_t tiles_x, n_tiles, rect_x0, rect_y0, rect_w, rect_h, world, rounds; };
+// how mesh tile i is dealt (rr_mesh_partition::rank0_rounds = j; the same arithmetic as rr_host_mesh_tile_home)
+#if defined(__HIPCC__)
+__device__ __forceinline__ void mesh_deal_owner(uint32_t i, uint32_t world, uint32_t j, uint32_t& rank, uint32_t& slot)
+{
+    if (j == 0u || world == 1u) { rank = i % world; slot = i / world; return; }
+    if (j == 0xffffffffu) { rank = 1u + i % (world - 1u); slot = i / (world - 1u); return; }
+    const uint32_t cl = j * (world - 1u) + 1u, c = i / cl, pos = i % cl;
+    if (pos == cl - 1u) { rank = 0u; slot = c; }
+    else { rank = 1u + pos % (world - 1u); slot = c * j + pos / (world - 1u); }
+}
+// the inverse for one rank: its slot k -> mesh tile index
+__device__ __forceinline__ uint32_t mesh_deal_index(uint32_t rank, uint32_t k, uint32_t world, uint32_t j)
+{
+    if (j == 0u || world == 1u) return k * world + rank;
+    if (j == 0xffffffffu) return k * (world - 1u) + (rank - 1u);            // (rank 0 holds no mesh tile)
+    const uint32_t cl = j * (world - 1u) + 1u;
+    if (rank == 0u) return k * cl + cl - 1u;
+    return (k / j) * cl + (k % j) * (world - 1u) + (rank - 1u);
+}
+#endif
 
 // k_stream_* (rr_render_stream.hip): the ray queues of one pass of the generation-per-kernel renderer
 constexpr uint32_t STREAM_MAX_GEN = 64;     // head counters: generations 0 .. max_refract + 1 <= 63

@@ -81,13 +81,21 @@ def assemble_host(gathered, width, height, world):
 
 def mesh_tile_home(part, t):
     """rr_mesh_partition: tile t -> ("mesh", rank, slot) or ("bg", 0, slot).  Mesh tiles (inside the rectangle, raster order,
-    index i) belong to rank i % world, slot i // world; every other tile to rank 0, in raster order."""
+    index i) are dealt to the ranks in turn, rank 0 -- which also renders every background tile -- taking fewer of them
+    (part.rank0_rounds); every other tile belongs to rank 0, in raster order."""
     tx, ty = t % part.tiles_x, t // part.tiles_x
-    if part.rect_w == 0:
-        return "mesh", t % part.world, t // part.world
-    if part.rect_x0 <= tx < part.rect_x0 + part.rect_w and part.rect_y0 <= ty < part.rect_y0 + part.rect_h:
-        i = (ty - part.rect_y0) * part.rect_w + (tx - part.rect_x0)
-        return "mesh", i % part.world, i // part.world
+    if part.rect_w == 0 or (part.rect_x0 <= tx < part.rect_x0 + part.rect_w and part.rect_y0 <= ty < part.rect_y0 + part.rect_h):
+        i = t if part.rect_w == 0 else (ty - part.rect_y0) * part.rect_w + (tx - part.rect_x0)
+        w, j = part.world, part.rank0_rounds
+        if j == 0 or w == 1:
+            return "mesh", i % w, i // w
+        if j == 0xffffffff:
+            return "mesh", 1 + i % (w - 1), i // (w - 1)
+        cl = j * (w - 1) + 1
+        c, pos = divmod(i, cl)
+        if pos == cl - 1:
+            return "mesh", 0, c
+        return "mesh", 1 + pos % (w - 1), c * j + pos // (w - 1)
     per_row = part.tiles_x - part.rect_w
     if ty < part.rect_y0:
         j = ty * part.tiles_x + tx
