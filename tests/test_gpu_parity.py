@@ -359,6 +359,67 @@ def test_lds_and_path_parallel_kernels_render_the_same_frames(tmp_path):
         assert a == b, tag
 
 
+def test_stream_renderer_renders_the_same_frames(tmp_path):
+    """k_stream_* (two-level scenes: one kernel per ray generation, rays in HBM queues, lanes refilled as their rays end, chains
+    followed in place) against the lock-step k_render_fused: every frame byte for byte, float colours bit for bit, the recursion's
+    counters equal -- instanced scenes with rotations, non-uniform scales, cull flags and a zero mask, a grid of 100 monkeys,
+    Depth 1 / 3 / 9, bounce limits from 0/0 to 12/2 (max_reflect decides which generation the chain kernel starts at), float
+    output, the tone map, and sharded tiles.  Own processes: the switch is read at rr_create."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import refraction_raytracing_dxr_amd as rr\n"
+        "from refraction_raytracing_dxr_amd.synth import asset, procedural_env\n"
+        "def xf(tx, ty, tz, s=(1, 1, 1), rot=0.0):\n"
+        "    c, sn = np.cos(rot), np.sin(rot)\n"
+        "    R = np.array([[c, 0, sn], [0, 1, 0], [-sn, 0, c]], np.float32) * np.array(s, np.float32)\n"
+        "    return np.concatenate([R, np.array([[tx], [ty], [tz]], np.float32)], axis=1)\n"
+        "r = rr.Renderer(0); out = []; cnt = []\n"
+        "ids = []\n"
+        "for name in ('cube.obj', 'monkey.obj', 'sphere.obj'):\n"
+        "    m = rr.Mesh(); m.load(asset(name)); i = r.upload_mesh(m.verts, m.indices); r.build_blas(i); ids.append(i)\n"
+        "r.upload_envmap(procedural_env(256, 128, seed=9))\n"
+        "scenes = [rr.make_instances(transforms=[xf(0, 0, 0), xf(0, 0, -2.5, (0.5, 0.8, 0.5), 0.4), xf(0.3, 0.2, 2.4, (0.7, 0.7, 0.7), -1.0), xf(0, 1.9, 0, (0.4, 0.4, 0.4), 0.2), xf(0, -1.8, 0.5, (0.5, 0.5, 0.5))],\n"
+        "                            meshes=[ids[1], ids[0], ids[1], ids[2], ids[0]], masks=[1, 1, 0xff, 1, 0], flags=[0, 0, 2, 1, 0]),\n"
+        "          rr.make_instances(transforms=[xf(1.1 * (i - 4.5), 0.3 * ((i + j) %% 3), 1.1 * (j - 4.5), (0.4, 0.4, 0.4), 0.3 * i) for i in range(10) for j in range(10)], meshes=[ids[1]] * 100)]\n"
+        "for si, inst in enumerate(scenes):\n"
+        "    r.build_tlas(inst)\n"
+        "    for depth, frames, kw, extra in ((1, 2, dict(max_refract=8), 0), (3, 3, dict(max_refract=5, max_reflect=1), 0), (9, 9, dict(max_refract=12), rr.DISPATCH_TONEMAP_REINHARD),\n"
+        "                                     (1, 1, dict(max_refract=0, max_reflect=0), 0), (2, 2, dict(max_refract=3, max_reflect=0), 0), (1, 1, dict(max_refract=1, max_reflect=2), 0)):\n"
+        "        r.render_orbit(211, 149, frames, angle=0.3 + si, params=rr.default_params(flags=rr.DISPATCH_COLLECT_STATS | rr.DISPATCH_FLOAT_OUTPUT | extra, **kw), frames_per_dispatch=depth)\n"
+        "        rgba, f32 = r.read_frame(want_float=True, slice=depth - 1)\n"
+        "        st = r.stats(); assert st.traversal_overflow == 0\n"
+        "        out += [rgba.view(np.uint32)[..., 0].astype(np.float64), f32[..., 0].astype(np.float64), f32[..., 2].astype(np.float64)]\n"
+        "        cnt += [st.rays, st.hits, st.misses, st.terminal_hits, st.tir, st.pixels, st.render_kernel]\n"
+        "    import ctypes as C\n"
+        "    mx = rr.dist.max_local_tiles(211, 149, 3); gathered = C.c_void_p(); rays = 0\n"
+        "    assert r._L.rr_device_alloc(r._h, 3 * mx * 4096, C.byref(gathered)) == 0\n"
+        "    for rank in range(3):\n"
+        "        r.set_tile_partition(rank, 3)\n"
+        "        r.dispatch_rays(211, 149, rr.default_params(max_refract=6))\n"
+        "        r.export_tiles(gathered.value + rank * mx * 4096); r.wait(); rays += r.stats().rays\n"
+        "    r.assemble_tiles(gathered.value, 3)\n"
+        "    out += [r.read_frame().view(np.uint32)[..., 0].astype(np.float64)]\n"
+        "    cnt += [rays]\n"
+        "    r._L.rr_device_free(r._h, gathered)\n"
+        "    r.set_tile_partition(0, 1)\n"
+        "np.save(sys.argv[1], np.stack(out)); print(' '.join(str(c) for c in cnt))\n") % ROOT
+    res = {}
+    for k in ("fused", "stream"):
+        env = dict(os.environ, RR_DEBUG_KERNEL=k)
+        p = subprocess.run([sys.executable, "-c", code, str(tmp_path / (k + ".npy"))], capture_output=True, text=True, env=env, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[k] = (np.load(tmp_path / (k + ".npy")), p.stdout.split())
+    assert np.array_equal(res["fused"][0], res["stream"][0])
+    a, b = res["fused"][1], res["stream"][1]
+    assert len(a) == len(b)
+    kernels = [int(b[i]) for i in range(len(b)) if i % 43 < 42 and (i % 43) % 7 == 6]
+    assert kernels and all(k == 7 for k in kernels), kernels          # the stream renderer really rendered every one of them
+    assert [x for i, x in enumerate(a) if not (i % 43 < 42 and (i % 43) % 7 == 6)] == [x for i, x in enumerate(b) if not (i % 43 < 42 and (i % 43) % 7 == 6)]
+
+
 def test_ploc_builder_makes_progress_on_equal_and_overflowing_areas(gpu):
     """The PREFER_FAST_TRACE builder merges mutually nearest clusters by merged-box area.  Identical triangles (every
     candidate area equal), a regular lattice (ties everywhere) and coordinates of 1e18 (areas near the top of fp32) must all
