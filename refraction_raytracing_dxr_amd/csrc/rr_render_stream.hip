@@ -10,11 +10,11 @@
 // steps 17 % -> ~50 %), and nothing of a pixel's state has to stay in registers while a ray is traced -- what made the
 // lane-asynchronous experiments of round 2 (every lane a state machine over its pixel's tree) lose what they gained.
 //
-//   generation 0   k_stream_rays<PRIMARY>: RayGen (hlsl:42-60) for the 8x8 pixel blocks of the tiles that touch the scene's
-//                  screen rectangle, traced in the same refill loop; every pixel gets a mark: its colour is the texel in slot 0
-//                  (Miss), black (no leaf below it), or the sum of its four leaf slots, zeroed here (it has children).
-//                  k_stream_background: the other blocks, one Miss per pixel without TraceRay (as k_render_fused's
-//                  background waves).
+//   generation 0   k_stream_primary: RayGen (hlsl:42-60) and the primary rays of the 8x8 pixel blocks of the tiles that touch the
+//                  scene's screen rectangle, in lock-step (primary rays stay together); every pixel gets a mark: its colour is
+//                  the texel in slot 0 (Miss), black (no leaf below it), or the sum of its four leaf slots, zeroed here (it has
+//                  children).  k_stream_background: the other blocks, one Miss per pixel without TraceRay (as
+//                  k_render_fused's background waves).
 //   generation g   k_stream_rays: ClosestHit (hlsl:79-125) pushes the refracted and the reflected child; Miss (hlsl:127-137)
 //                  writes (weight, texel) to the ray's leaf slot.  The tree only branches while count < max_reflect <= 2, so
 //                  a pixel has at most four root-to-leaf paths; slot = path bits (reflect at count 0: 2, at count 1: 1), which
@@ -109,44 +109,90 @@ __device__ __forceinline__ void stream_shade_hit(const SceneDev& sc, const Dispa
 }
 
 // ---------------------------------------------------------------------------------------------------
-// RayGen (RayTracing.hlsl:42-60) for the blocks the ray kernels render: pixel ordinal = wave-block * 64 + Morton position ->
-// entry of queue 0.  A pixel beyond the frame's edge gets an INVALID entry; the pixels of a block outside the scene's screen
-// rectangle are marked UNTRACED (their primary ray is a Miss by construction).
-constexpr uint32_t META_INSIDE = 0x10000u, META_UNTRACED = 0x20000u, META_INVALID = 0xffffffffu;
+// Generation 0: RayGen (RayTracing.hlsl:42-60) and the primary rays of the blocks of the tiles that touch the rectangle, traced in
+// LOCK-STEP, one 8x8 pixel block per wave trip -- the 64 primary rays of a block are the one kind of ray that stays together
+// (lane utilisation of the node steps 60-80 %), so the refill machinery would only add its queue round trip to them.  Persistent
+// waves draw blocks from the generation's ticket counters; the children go to queue 1 through the wave's block reservation.
+// Every pixel gets its mark for the resolve kernel: its colour is the texel in slot 0 (Miss), black (no leaf below it), or the sum
+// of its four leaf slots, zeroed here (it has children).  Pixel ordinal = wave-block * 64 + Morton position.
+constexpr uint32_t META_INSIDE = 0x10000u;
 
-template <bool STATS>
-__global__ __launch_bounds__(256) void k_stream_raygen(DispatchDev a, StreamDev s)
+template <int STACK, bool STATS, class E, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_stream_primary(SceneDev sc, DispatchDev a, StreamDev s)
 {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    const uint32_t wb = blockIdx.x * 4u + wave;
-    if (wb >= s.n_rect_wb) return;
-    const BlockPos bp = wave_block_pos(a, wb);
-    const uint32_t x = bp.x0 + compact1by1(lane), y = bp.y0 + compact1by1(lane >> 1);
-    const bool ok = bp.tile_ok && x < a.W && y < a.H;
-    const bool may_hit = bp.x0 + 8u > a.hx0 && bp.x0 < a.hx1 && bp.y0 + 8u > a.hy0 && bp.y0 < a.hy1;
-    const uint32_t cov = wb * 64u + lane;
-    float4* q = s.q[0] + (size_t)cov * 3;
-    if (ok) {
-        const CamDev& cb = a.cams[bp.frame];
-        const f3 D = camera_ray_dir(cb.M, a.sx[x], a.sy[y]);
-        q[0] = make_float4(cb.cam[0], cb.cam[1], cb.cam[2], 1.0f);
-        q[1] = make_float4(D.x, D.y, D.z, __uint_as_float(cov));
-        q[2] = make_float4(__uint_as_float(may_hit ? 0u : META_UNTRACED), 0.0f, 0.0f, 0.0f);
-    } else {
-        q[2] = make_float4(__uint_as_float(META_INVALID), 0.0f, 0.0f, 0.0f);
-    }
-    if (lane == 0) {
-        s.fill[0][wb] = 64u;
-        if (STATS && bp.tile_ok) {      // counted as k_render_fused counts them: every block of the frame's tiles, and those outside the rectangle
-            atomicAdd(&a.counters[C_WAVES], 1ull);
-            if (!may_hit) atomicAdd(&a.counters[C_BG_WAVES], 1ull);
+    E* const stk = reinterpret_cast<E*>(lds) + wave * (STACK * 64) + lane;
+    uint32_t* const tickets = s.next;                                   // generation 0's counters
+    LaneStats st;
+    stats_clock_begin<STATS>(st);
+    uint32_t shard;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(shard));
+    shard &= 7u;
+    uint32_t shards_left = 8u;
+    uint32_t ob = SQ_NONE, ou = 0u;
+    const uint32_t lx = compact1by1(lane), ly = compact1by1(lane >> 1);
+    for (;;) {
+        uint32_t wb = 0xffffffffu;
+        while (shards_left != 0u) {
+            uint32_t t = 0;
+            if (lane == 0u) t = atomicAdd(&tickets[shard * 16u], 1u);
+            t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+            const uint32_t c = t * 8u + shard;
+            if (c < s.n_rect_wb) { wb = c; break; }
+            shard = (shard + 1u) & 7u; --shards_left;
         }
+        if (wb == 0xffffffffu) break;
+        const BlockPos bp = wave_block_pos(a, wb);
+        if (!bp.tile_ok) continue;
+        const uint32_t x = bp.x0 + lx, y = bp.y0 + ly;
+        const bool valid = x < a.W && y < a.H;
+        const bool may_hit = bp.x0 + 8u > a.hx0 && bp.x0 < a.hx1 && bp.y0 + 8u > a.hy0 && bp.y0 < a.hy1;
+        st.blocks += 1u;
+        if (STATS && !may_hit) st.bg_blocks += 1u;
+        const uint32_t cov = wb * 64u + lane;
+        bool refr = false, refl = false;
+        f3 X = mk3(0.0f, 0.0f, 0.0f);
+        StreamChild c1, c2;
+        c1.D = c2.D = X; c1.w = c2.w = 0.0f; c1.meta = c2.meta = 0u;
+        if (valid) {
+            const CamDev& cb = a.cams[bp.frame];
+            const f3 O = mk3(cb.cam[0], cb.cam[1], cb.cam[2]);
+            const f3 D = camera_ray_dir(cb.M, a.sx[x], a.sy[y]);
+            st.pixels += 1; ++st.rays;
+            if (STATS && first_active_lane()) ++st.passes;
+            HitRec h;
+            h.hit = false;
+            if (may_hit) trace_scene<STATS, true, E, GlobalNodes>(sc, O, D, a.tmin_p, a.tmax_p, CULL_BACK, h, stk, st.cnt);
+            if (!h.hit) {                                               // the pixel's only leaf: payload.color = 0 + 1 * texel
+                if (STATS) ++st.miss;
+                const f3 e = env_lookup(sc, D);
+                s.slots[(size_t)cov * 4] = make_float4(1.0f, e.x, e.y, e.z);
+                s.pending[cov] = PIX_ONE_LEAF;
+            } else {
+                if (STATS) ++st.hits;
+                if (0 < a.max_refract) {                                // hlsl:82 at count 0
+                    stream_shade_hit(sc, a, O, D, 1.0f, 0u, true, 0u, h, X, refr, refl, c1, c2);
+                    if (STATS && !refr) ++st.tir;
+                } else if (STATS) ++st.term;                            // payload.color stays 0
+                if (refr || refl) {
+                    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    float4* sl = s.slots + (size_t)cov * 4;
+                    sl[0] = z; sl[1] = z; sl[2] = z; sl[3] = z;
+                    s.pending[cov] = PIX_LEAVES;
+                } else s.pending[cov] = PIX_BLACK;                      // no leaf below this pixel
+            }
+        }
+        sq_push(s, 1u, ob, ou, refr, X, c1.D, c1.w, cov, c1.meta, lane, a.error_flag);
+        sq_push(s, 1u, ob, ou, refl, X, c2.D, c2.w, cov, c2.meta, lane, a.error_flag);
     }
+    if (ob != SQ_NONE && ob != SQ_DEAD) sq_finalize(s, 1u, ob, ou, lane);
+    flush_stats<STATS>(a, st, blockIdx.x * 4u + wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
-// One ray kernel.  MODE 0: generation 0 (the rays RayGen made; marks every pixel for the resolve kernel).  MODE 1: a generation
-// whose rays still branch (count < max_reflect): both children go to the next queue.  MODE 2: every later generation at once --
+// One ray kernel (generations 1 and up).  MODE 1: a generation whose rays still branch (count < max_reflect): both children go
+// to the next queue.  MODE 2: every later generation at once --
 // from count == max_reflect on a ray has at most ONE child (the refracted one), so the lane follows the chain itself: the child
 // overwrites the parent's queue entry (the lane owns it) and is traced next, nothing is queued, no generation has to end before
 // the next begins.
@@ -175,8 +221,7 @@ __global__ __launch_bounds__(256, WPS) void k_stream_rays(SceneDev sc, DispatchD
     float4* const qin = s.q[gen & 1u];
     const uint32_t* __restrict__ fin = s.fill[gen & 1u];
     uint32_t n_chunks;
-    if (MODE == 0) n_chunks = s.n_rect_wb;
-    else { uint32_t h = s.heads[gen]; h = h < s.cap ? h : s.cap; n_chunks = h >> 6; }
+    { uint32_t h = s.heads[gen]; h = h < s.cap ? h : s.cap; n_chunks = h >> 6; }
     uint32_t* const tickets = s.next + (size_t)gen * (8u * 16u);
     const uint32_t n_tris = sc.n_pool_tris;
 
@@ -216,7 +261,7 @@ __global__ __launch_bounds__(256, WPS) void k_stream_rays(SceneDev sc, DispatchD
     for (;;) {
         const bool more = shards_left != 0u || (chunk != NO_CHUNK && off < nv);
         int pick = -1;                                  // nothing is worth issuing: the step most lanes wait for runs alone
-        int serve, need_lanes;
+        int serve, need_lanes, node_need;
         {
             const uint32_t un = (uint32_t)node;
             const bool at_leaf = un > ST_IDLE;
@@ -225,9 +270,10 @@ __global__ __launch_bounds__(256, WPS) void k_stream_rays(SceneDev sc, DispatchD
             const int n_shade = n_fin + (more ? n_idle : 0);
             if (n_node + n_tri + n_ent + n_exit + n_shade == 0) break;
             const int n_alive = 64 - (more ? 0 : n_idle);
-            serve = (n_alive * (int)a.async_leaf_num + 15) / 16;
+            serve = (n_alive * (int)(a.async_leaf_num & 0xffu) + 15) / 16;
             need_lanes = (n_alive * (int)a.async_shade_num + 15) / 16;
-            if (n_node < serve * 2 && n_tri < serve && n_ent < serve && n_exit < serve && (n_shade < need_lanes || n_shade == 0)) {
+            node_need = (a.async_leaf_num >> 8) ? serve * (int)(a.async_leaf_num >> 8) / 2 : serve * 2;     // (experiments: the node loop's share in halves of `serve`)
+            if (n_node < node_need && n_tri < serve && n_ent < serve && n_exit < serve && (n_shade < need_lanes || n_shade == 0)) {
                 pick = 0; int mx = n_node;
                 if (n_tri > mx) { mx = n_tri; pick = 1; }
                 if (n_ent > mx) { mx = n_ent; pick = 2; }
@@ -238,9 +284,9 @@ __global__ __launch_bounds__(256, WPS) void k_stream_rays(SceneDev sc, DispatchD
         // ---- internal-node steps
         {
             const int n_node = __popcll(__ballot(node >= 0));
-            if (n_node > 0 && (n_node >= serve * 2 || pick == 0)) {
+            if (n_node > 0 && (n_node >= node_need || pick == 0)) {
                 if (node >= 0) {
-                    const int stop = pick == 0 ? (n_node + 1) / 2 : serve * 2 - 1;         // go on while at least 2 * serve lanes descend
+                    const int stop = pick == 0 ? (n_node + 1) / 2 : node_need - 1;         // go on while at least 2 * serve lanes descend
                     do {
                         const NodeQ q = load_node(nodes, node);
                         if (STATS) { st.cnt.nodes++; if (first_active_lane()) st.cnt.node_trips++; }
@@ -341,7 +387,6 @@ __global__ __launch_bounds__(256, WPS) void k_stream_rays(SceneDev sc, DispatchD
                         if (STATS) ++st.miss;
                         const f3 e = env_lookup(sc, D);
                         s.slots[(size_t)cov * 4 + slot] = make_float4(w, e.x, e.y, e.z);
-                        if (MODE == 0) s.pending[cov] = PIX_ONE_LEAF;           // the pixel's only leaf: payload.color = 0 + 1 * texel
                     } else {
                         if (STATS) ++st.hits;
                         const InstDev& in = sc.insts[best.inst];                // the ray in the space of the instance that was hit
@@ -352,14 +397,6 @@ __global__ __launch_bounds__(256, WPS) void k_stream_rays(SceneDev sc, DispatchD
                             stream_shade_hit(sc, a, O, D, w, count, outside, slot, best, X, refr, refl, c1, c2);
                             if (STATS && !refr) ++st.tir;
                         } else if (STATS) ++st.term;                            // payload.color stays 0
-                        if (MODE == 0) {
-                            if (refr || refl) {
-                                const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                                float4* sl = s.slots + (size_t)cov * 4;
-                                sl[0] = z; sl[1] = z; sl[2] = z; sl[3] = z;
-                                s.pending[cov] = PIX_LEAVES;
-                            } else s.pending[cov] = PIX_BLACK;                  // no leaf below this pixel
-                        }
                         if (MODE == 2 && refr) {                                // the chain goes on in this lane, in this queue entry
                             qin[(size_t)rid * 3] = make_float4(X.x, X.y, X.z, c1.w);
                             qin[(size_t)rid * 3 + 1] = make_float4(c1.D.x, c1.D.y, c1.D.z, __uint_as_float(cov));
@@ -395,16 +432,13 @@ __global__ __launch_bounds__(256, WPS) void k_stream_rays(SceneDev sc, DispatchD
                     if (node == TRAV_IDLE && rank < left) {
                         const uint32_t r = chunk * 64u + off + rank;
                         const uint32_t m = __float_as_uint(qin[(size_t)r * 3 + 2].x);
-                        if (m != META_INVALID) {
-                            const float4 q0 = qin[(size_t)r * 3], q1 = qin[(size_t)r * 3 + 1];
-                            rid = r;
-                            if (MODE == 0) st.pixels += 1;
-                            start_ray(mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), (m & META_INSIDE) != 0u, (m & META_UNTRACED) == 0u);
-                        }
+                        const float4 q0 = qin[(size_t)r * 3], q1 = qin[(size_t)r * 3 + 1];
+                        rid = r;
+                        start_ray(mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), (m & META_INSIDE) != 0u, true);
                     }
                     const uint32_t asked = (uint32_t)__popcll(need);
                     off += asked < left ? asked : left;
-                    need = __ballot(node == TRAV_IDLE);          // (a lane that drew an off-frame pixel is still idle and draws again)
+                    need = __ballot(node == TRAV_IDLE);
                 }
             }
         }
@@ -483,11 +517,10 @@ static hipError_t launch_stream_sw(const SceneDev& sc, const DispatchDev& a, con
     if (e != hipSuccess) return e;
     if (s.n_rect_wb < total_wb)
         hipLaunchKernelGGL((k_stream_background<STATS>), dim3((total_wb - s.n_rect_wb + 3u) / 4u), dim3(256), 0, st, sc, a, s);
-    hipLaunchKernelGGL((k_stream_raygen<STATS>), dim3((s.n_rect_wb + 3u) / 4u), dim3(256), 0, st, a, s);
-    hipLaunchKernelGGL((k_stream_rays<STACK, STATS, E, 0, WPS>), dim3(n_wg), dim3(256), lds, st, sc, a, s, 0u, a.tmin_p, a.tmax_p);
+    hipLaunchKernelGGL((k_stream_primary<STACK, STATS, E, WPS>), dim3(n_wg), dim3(256), (size_t)4 * STACK * 64 * sizeof(E), st, sc, a, s);
     // generations that still branch push to the next queue; from count == max_reflect on one kernel follows every chain to its end
     const int chain_gen = a.max_reflect < 1 ? 1 : a.max_reflect;
-    int launches = 1;
+    int launches = 0;
     for (int g = 1; g <= a.max_refract && g < chain_gen; ++g, ++launches)
         hipLaunchKernelGGL((k_stream_rays<STACK, STATS, E, 1, WPS>), dim3(n_wg), dim3(256), lds, st, sc, a, s, (uint32_t)g, a.tmin_s, a.tmax_s);
     if (chain_gen <= a.max_refract) {
@@ -495,7 +528,7 @@ static hipError_t launch_stream_sw(const SceneDev& sc, const DispatchDev& a, con
         ++launches;
     }
     hipLaunchKernelGGL(k_stream_resolve, dim3((s.n_rect_wb + 3u) / 4u), dim3(256), 0, st, a, s);
-    snprintf(g_stream_name, sizeof g_stream_name, "k_stream_rays<%d, %s, unsigned short, 0|1|2, %d> x %d launches", STACK, STATS ? "true" : "false", WPS, launches);
+    snprintf(g_stream_name, sizeof g_stream_name, "k_stream_primary + k_stream_rays<%d, %s, unsigned short, 1|2, %d> x %d", STACK, STATS ? "true" : "false", WPS, launches);
     return hipGetLastError();
 }
 
