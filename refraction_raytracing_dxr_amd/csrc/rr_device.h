@@ -234,15 +234,17 @@ __device__ __forceinline__ void box2_hit(const BoxRay& r, const NodeQ& n, float 
 // followed, far child pushed), and the host picks a stack at least that deep, so there is no overflow check.
 constexpr int STACK_STRIDE = 64;
 // Stack entries are child refs.  32-bit entries hold them as they are; 16-bit entries (meshes below 32 768 triangles:
-// a quarter of the LDS per wave, so deep trees keep eight waves per SIMD) hold node index or 0x8000 | leaf index.
+// a quarter of the LDS per wave, so deep trees keep eight waves per SIMD) hold a SIGNED half: node index (>= 0) or ~leaf
+// (< 0).  A ref is a byte offset (a multiple of 32) or ~leaf, so packing is min(ref >> 5, ref) and unpacking max(v << 5, v)
+// of the sign-extended entry: two instructions each way.
 template <class E> struct StackCodec;
 template <> struct StackCodec<uint32_t> {
     static __device__ __forceinline__ uint32_t enc(int ref) { return (uint32_t)ref; }
     static __device__ __forceinline__ int dec(uint32_t v) { return (int)v; }
 };
 template <> struct StackCodec<uint16_t> {
-    static __device__ __forceinline__ uint16_t enc(int ref) { return ref >= 0 ? (uint16_t)((uint32_t)ref >> 5) : (uint16_t)(0x8000u | (uint32_t)~ref); }
-    static __device__ __forceinline__ int dec(uint16_t v) { return (v & 0x8000u) ? ~(int)(v & 0x7fffu) : (int)((uint32_t)v << 5); }
+    static __device__ __forceinline__ uint16_t enc(int ref) { const int n = ref >> 5; return (uint16_t)(n < ref ? n : ref); }
+    static __device__ __forceinline__ int dec(uint16_t v) { const int s = (int)(int16_t)v, n = s << 5; return n > s ? n : s; }
 };
 
 // one traversal step at an internal node: returns the next node (near child, or a popped entry, or

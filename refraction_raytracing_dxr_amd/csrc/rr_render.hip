@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256, TLAS ? 5 : 8) void k_render_paths(SceneDev sc,
 // in runs of strips.  Tickets come from LDS_QUEUES counters per phase (rr_types.h); a wave whose own queue is empty drains
 // the others, so every block is rendered whatever the placement of workgroups is.
 // NW waves per workgroup, WGS workgroups per CU (NW * WGS / 4 waves per SIMD); stack entries are 16 bits (node index or
-// 0x8000 | leaf index: an LDS-resident array has fewer than 5 120 nodes).  After the last block the last wave to leave
+// ~leaf index: an LDS-resident array has fewer than 5 120 nodes).  After the last block the last wave to leave
 // zeroes the ticket words, so the next launch on the same slot needs no memset.
 template <int NW, int WGS, bool STATS, bool DIAG = false>
 __global__ __launch_bounds__(NW * 64, NW * WGS / 4) void k_render_lds(SceneDev sc, DispatchDev a, LdsDispatch q)
