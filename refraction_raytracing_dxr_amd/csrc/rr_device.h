@@ -340,14 +340,12 @@ __device__ __forceinline__ bool leaf_phase_due(int n_in)
 // them hold a leaf or have finished (leaf_phase_due); then the (expensive) triangle test is executed once for
 // all lanes that hold a leaf.
 template <bool STATS, class E, class NS = GlobalNodes>
-__device__ __forceinline__ void trace_blas(const BlasDev& bl, f3 O, f3 D, float tmin, uint32_t cull, uint32_t inst,
-                                           HitRec& best, E* stk, TravCounters& cnt, const Diag dg = Diag{ nullptr },
-                                           const NS ns = NS{})
+__device__ __forceinline__ void walk_blas(const QNode* __restrict__ nodes, const TriRec* __restrict__ tris, int root, const BoxRay& br,
+                                          f3 O, f3 D, float tmin, uint32_t cull, uint32_t inst, HitRec& best, E* stk,
+                                          TravCounters& cnt, const Diag dg = Diag{ nullptr }, const NS ns = NS{})
 {
-    const BoxRay br = box_ray(O, D, bl.scale, bl.grid);
-    const QNode* __restrict__ nodes = bl.nodes;
     E* top = stk;
-    int node = 0;
+    int node = root;
     for (;;) {
         // internal-node phase.  Lanes drop out as they reach a leaf (or finish); the phase ends for the whole wave
         // once a quarter of the lanes that entered it have dropped out (see leaf_phase_due), not when the last one
@@ -370,11 +368,20 @@ __device__ __forceinline__ void trace_blas(const BlasDev& bl, f3 O, f3 D, float 
         if (node < 0 && node != TRAV_DONE) {
             diag_trip(dg, 1);
             if (STATS) { cnt.tris++; if (first_active_lane()) cnt.leaf_trips++; }
-            tri_test(bl.tris, (uint32_t)~node, O, D, tmin, cull, inst, best);
+            tri_test(tris, (uint32_t)~node, O, D, tmin, cull, inst, best);
             if (top > stk) { top -= STACK_STRIDE; node = StackCodec<E>::dec(*top); } else node = TRAV_DONE;
         }
         if (__ballot(node != TRAV_DONE) == 0ull) break;
     }
+}
+
+template <bool STATS, class E, class NS = GlobalNodes>
+__device__ __forceinline__ void trace_blas(const BlasDev& bl, f3 O, f3 D, float tmin, uint32_t cull, uint32_t inst,
+                                           HitRec& best, E* stk, TravCounters& cnt, const Diag dg = Diag{ nullptr },
+                                           const NS ns = NS{})
+{
+    const BoxRay br = box_ray(O, D, bl.scale, bl.grid);
+    walk_blas<STATS, E, NS>(bl.nodes, bl.tris, 0, br, O, D, tmin, cull, inst, best, stk, cnt, dg, ns);
     if (best.hit) hit_attributes(bl.tris, O, D, best);
 }
 
@@ -492,9 +499,13 @@ __device__ __forceinline__ f3 xform_dir(const float* m, f3 p)
 }
 
 // TraceRay(Scene, flags, 0xff, 0,0,0, ray, payload): closest hit over TLAS -> BLAS.
-// TLAS = false: the reference's scene, one BLAS.  TLAS = true: one loop over the flattened node pool;
-// reaching an instance leaf swaps the lane's ray for its object-space image (t is preserved: the
-// direction is not renormalised) and remembers the stack level, exhausting that level swaps it back.
+// TLAS = false: the reference's scene, one BLAS.  TLAS = true: the wave walks the top level in world space until every lane
+// holds an instance leaf or has finished; the lanes at a leaf then walk their instances (walk_blas: the single-BLAS loop with
+// its early hand-over, on the ray's object-space image -- t is preserved, the direction is not renormalised -- with the
+// top level's entries left below on the stack) and pop the next top-level entry.  Equal-t ties go to the lower (instance,
+// primitive), so the order instances are visited in does not matter.  (Rounds 1-2 walked both levels in ONE loop over the
+// flattened pool, so that a lane leaving an instance need not wait for the others; with a leaf part that tests triangles,
+// enters and leaves instances it cost more than the waiting: C4 0.96 -> 0.90 ms, C5 on this kernel 6.8 -> 6.1.)
 template <bool STATS, bool TLAS, class E = uint32_t, class NS = GlobalNodes>
 __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, float tmin, float tmax, uint32_t flags,
                                             HitRec& best, E* stk_e, TravCounters& cnt,
@@ -508,50 +519,34 @@ __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, floa
     }
     E* stk = stk_e;                         // (16-bit entries: scenes of fewer than 32 768 pool nodes and triangles + instances)
     const QNode* __restrict__ nodes = sc.pool_nodes;
-    constexpr uint32_t NO_INST = 0xffffffffu;
-    BoxRay br = box_ray(O, D, sc.scale, sc.grid);
-    f3 Oc = O, Dc = D;                      // the ray in the space of the level being walked
-    uint32_t cull = flags, cur = NO_INST;
     E* top = stk;
-    const E* floor = stk;                   // floor: stack level at which the current instance was entered
     int node = 0;
+    const BoxRay br = box_ray(O, D, sc.scale, sc.grid);
     for (;;) {
-        while (node >= 0) {                     // (the early hand-over of trace_blas costs 13-16 % here: C4, C5 measured)
+        while (node >= 0) {
             const NodeQ q = load_node(nodes, node);
             if (STATS) { cnt.nodes++; if (first_active_lane()) cnt.node_trips++; }
-            node = node_step(br, q, tmin, best.t, top, floor);
+            node = node_step(br, q, tmin, best.t, top, stk);
         }
-        if (node == TRAV_DONE) {
-            if (cur == NO_INST) break;
-            cur = NO_INST; Oc = O; Dc = D; cull = flags; floor = stk;        // leave the instance
-            br = box_ray(O, D, sc.scale, sc.grid);
-            if (top > stk) { top -= STACK_STRIDE; node = StackCodec<E>::dec(*top); continue; }
-            break;
+        if (node == TRAV_DONE) break;
+        if (STATS && first_active_lane()) cnt.leaf_trips++;
+        const uint32_t ii = (uint32_t)~node - sc.n_pool_tris;               // a leaf of the top level is an instance
+        const InstDev& in = sc.insts[ii];
+        if (in.mask & 0xffu) {
+            uint32_t f = flags;
+            if (in.flags & 0x1u) f &= ~(CULL_BACK | CULL_FRONT);
+            else if (in.flags & 0x2u) {
+                if (f & CULL_BACK) f = (f & ~CULL_BACK) | CULL_FRONT;
+                else if (f & CULL_FRONT) f = (f & ~CULL_FRONT) | CULL_BACK;
+            }
+            f3 Oc = O, Dc = D;
+            if (!in.identity) { Oc = xform_point(in.inv, O); Dc = xform_dir(in.inv, D); }
+            const BoxRay bi = box_ray(Oc, Dc, in.scale, in.grid);
+            walk_blas<STATS, E, GlobalNodes>(nodes, sc.pool_tris, (int)in.root, bi, Oc, Dc, tmin, f, ii, best, top, cnt);
         }
-        const uint32_t L = (uint32_t)~node;
-        if (STATS && first_active_lane()) cnt.leaf_trips++;          // a trip of the two-level loop's leaf part: triangle tests and instance entries
-        if (L < sc.n_pool_tris) {
-            if (STATS) cnt.tris++;
-            tri_test(sc.pool_tris, L, Oc, Dc, tmin, cull, cur, best);
-            if (top > floor) { top -= STACK_STRIDE; node = StackCodec<E>::dec(*top); } else node = TRAV_DONE;
-        } else {
-            const uint32_t ii = L - sc.n_pool_tris;
-            const InstDev& in = sc.insts[ii];
-            if (in.mask & 0xffu) {                                            // InstanceInclusionMask 0xff
-                uint32_t f = flags;
-                if (in.flags & 0x1u) f &= ~(CULL_BACK | CULL_FRONT);          // TRIANGLE_CULL_DISABLE
-                else if (in.flags & 0x2u) {                                    // TRIANGLE_FRONT_COUNTERCLOCKWISE
-                    if (f & CULL_BACK) f = (f & ~CULL_BACK) | CULL_FRONT;
-                    else if (f & CULL_FRONT) f = (f & ~CULL_FRONT) | CULL_BACK;
-                }
-                cull = f; cur = ii; floor = top;
-                if (!in.identity) { Oc = xform_point(in.inv, O); Dc = xform_dir(in.inv, D); }
-                br = box_ray(Oc, Dc, in.scale, in.grid);
-                node = (int)in.root;
-            } else if (top > stk) { top -= STACK_STRIDE; node = StackCodec<E>::dec(*top); } else node = TRAV_DONE;
-        }
+        if (top > stk) { top -= STACK_STRIDE; node = StackCodec<E>::dec(*top); } else node = TRAV_DONE;
     }
-    if (best.hit) {                             // the ray in the space of the instance that was hit, as at its entry
+    if (best.hit) {
         const InstDev& in = sc.insts[best.inst];
         f3 Oh = O, Dh = D;
         if (!in.identity) { Oh = xform_point(in.inv, O); Dh = xform_dir(in.inv, D); }

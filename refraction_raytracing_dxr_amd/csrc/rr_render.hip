@@ -714,8 +714,14 @@ static hipError_t launch_fused_tlas16(const SceneDev& sc, const DispatchDev& a, 
 hipError_t launch_render_fused(const SceneDev& sc, const DispatchDev& a, int stack, int pend, bool stats, hipStream_t s, bool stack16)
 {
     if (a.n_blocks == 0) return hipSuccess;
-    if (stack16 && !a.diag && !sc.single_identity && pend <= 2 && stack <= 30) return launch_fused_tlas16<30, 7>(sc, a, stats, s);
-    if (stack16 && !a.diag && !sc.single_identity && pend <= 2 && stack <= 39) return launch_fused_tlas16<39, 5>(sc, a, stats, s);
+#ifndef RR_TLAS30_WPS
+#define RR_TLAS30_WPS 7
+#endif
+#ifndef RR_TLAS39_WPS
+#define RR_TLAS39_WPS 5
+#endif
+    if (stack16 && !a.diag && !sc.single_identity && pend <= 2 && stack <= 30) return launch_fused_tlas16<30, RR_TLAS30_WPS>(sc, a, stats, s);
+    if (stack16 && !a.diag && !sc.single_identity && pend <= 2 && stack <= 39) return launch_fused_tlas16<39, RR_TLAS39_WPS>(sc, a, stats, s);
     if (stack16 && !a.diag && sc.single_identity && stack <= 39)
         return pend <= 2 ? launch_fused_s16<2>(sc, a, stats, s) : launch_fused_s16<8>(sc, a, stats, s);
     if (a.diag) {       // diagnostic build of the reference-scene kernel (RR_DEBUG_DIAG; never used by the product path)
