@@ -498,6 +498,18 @@ __device__ __forceinline__ f3 xform_dir(const float* m, f3 p)
                (m[8] * p.x + m[9] * p.y) + m[10] * p.z);
 }
 
+// The record of instance ii.  When every active lane asks for the same instance (the common case of a wave whose rays stay
+// together: C4) the index is wave-uniform and the 96 bytes come through the scalar cache once, instead of 64 lanes x 96 B
+// through the texture path, which the node fetches already keep > 90 % busy (profiles/r03_pmc_c4_fused.txt).
+__device__ __forceinline__ InstDev inst_record(const InstDev* __restrict__ insts, uint32_t ii)
+{
+    const uint32_t iu = (uint32_t)__builtin_amdgcn_readfirstlane((int)ii);
+    InstDev r;
+    if (__ballot(ii != iu) == 0ull) r = insts[iu];
+    else r = insts[ii];
+    return r;
+}
+
 // TraceRay(Scene, flags, 0xff, 0,0,0, ray, payload): closest hit over TLAS -> BLAS.
 // TLAS = false: the reference's scene, one BLAS.  TLAS = true: the wave walks the top level in world space until every lane
 // holds an instance leaf or has finished; the lanes at a leaf then walk their instances (walk_blas: the single-BLAS loop with
@@ -531,7 +543,7 @@ __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, floa
         if (node == TRAV_DONE) break;
         if (STATS && first_active_lane()) cnt.leaf_trips++;
         const uint32_t ii = (uint32_t)~node - sc.n_pool_tris;               // a leaf of the top level is an instance
-        const InstDev& in = sc.insts[ii];
+        const InstDev in = inst_record(sc.insts, ii);
         if (in.mask & 0xffu) {
             uint32_t f = flags;
             if (in.flags & 0x1u) f &= ~(CULL_BACK | CULL_FRONT);
@@ -547,7 +559,7 @@ __device__ __forceinline__ void trace_scene(const SceneDev& sc, f3 O, f3 D, floa
         if (top > stk) { top -= STACK_STRIDE; node = StackCodec<E>::dec(*top); } else node = TRAV_DONE;
     }
     if (best.hit) {
-        const InstDev& in = sc.insts[best.inst];
+        const InstDev in = inst_record(sc.insts, best.inst);
         f3 Oh = O, Dh = D;
         if (!in.identity) { Oh = xform_point(in.inv, O); Dh = xform_dir(in.inv, D); }
         hit_attributes(sc.pool_tris, Oh, Dh, best);
@@ -614,8 +626,9 @@ __device__ __forceinline__ f3 shading_normal(const SceneDev& sc, const HitRec& h
     f3 A = mk3(a.x, a.y, a.z);
     f3 BA = sub3(mk3(b.x, b.y, b.z), A), CA = sub3(mk3(c.x, c.y, c.z), A);
     f3 Nr = mk3(fmaf(v, CA.x, fmaf(u, BA.x, A.x)), fmaf(v, CA.y, fmaf(u, BA.y, A.y)), fmaf(v, CA.z, fmaf(u, BA.z, A.z)));
-    if (TLAS && !sc.insts[h.inst].identity) {
-        const float* w = sc.insts[h.inst].inv;
+    const InstDev in = TLAS ? inst_record(sc.insts, h.inst) : InstDev{};
+    if (TLAS && !in.identity) {
+        const float* w = in.inv;
         Nr = mk3((w[0] * Nr.x + w[4] * Nr.y) + w[8] * Nr.z,
                  (w[1] * Nr.x + w[5] * Nr.y) + w[9] * Nr.z,
                  (w[2] * Nr.x + w[6] * Nr.y) + w[10] * Nr.z);

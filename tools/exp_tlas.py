@@ -1,5 +1,5 @@
 """C4 / C5 (two-level scenes) on whichever renderer RR_DEBUG_KERNEL selects: python tools/exp_tlas.py [C4|C5|both] [depth]
-HIP-event kernel time per frame, exact trip counters of the STATS build."""
+HIP-event kernel time per frame, exact trip counters of the STATS build (PROF=1: no stats launch, for counter passes)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -40,6 +40,8 @@ for label, names, inst, W, H, refr, radius in cases:
     st = r.stats()
     us = ms / n * 1e3 / depth
     name = st.render_kernel_name.decode()
+    if os.environ.get("PROF") == "1":          # under a counter pass: only the timed launches (the stats build is another kernel)
+        print("%s depth %d: %8.1f us/frame | %s" % (label, depth, us, name), flush=True); continue
     r.dispatch_rays_batch(W, H, cams, rr.default_params(max_refract=refr, flags=rr.DISPATCH_COLLECT_STATS))
     ss = r.stats()
     print("%s depth %d: %8.1f us/frame %6.2f Grays/s  %.2f Mrays/frame | %s | node trips %.1f M/frame (lanes %.3f) leaf trips %.1f M (%.3f) passes %.2f M (%.3f) overflow %d" % (
