@@ -79,7 +79,8 @@ static_assert(sizeof(InstDev) == 96, "InstDev must be 96 B");
 // Scenes beyond the reference's single identity instance are FLATTENED at rr_build_tlas: the TLAS nodes
 // and the nodes of every BLAS in use live in one node pool (child refs rebased), triangles and normals
 // in one pool each.  A leaf ref ~L is a triangle for L < n_pool_tris and instance L - n_pool_tris
-// otherwise, so one traversal loop walks both levels.
+// otherwise: one base address and one kind of stack entry for both levels (the lock-step kernels walk the levels nested,
+// trace_scene; the stream renderer's lanes are at either level independently).
 struct SceneDev {
     BlasDev  blas0;           // used directly when the scene is one identity instance (the reference's case)
     const QNode* pool_nodes;      // [0, n_insts-1): TLAS (on the scene grid), then the BLASes (each on its own grid)
