@@ -781,14 +781,19 @@ constexpr uint32_t STREAM_BLK = 1024;
 
 struct StreamPlan { uint32_t fc, n_wg; size_t cap, pixels; };
 
+// wave-blocks of `frames` slices that the ray kernels render: the tiles that touch the scene's screen rectangle come first in
+// launch order (under the mesh-tile partition: this rank's mesh tiles), in groups of eight tiles
+size_t stream_rect_wb(const DispatchDev& a, uint32_t frames)
+{
+    const size_t all = (size_t)a.blocks_per_frame * frames * 4u;
+    if (!a.mesh_part && a.rt_w == 0u) return all;
+    const size_t tiles = a.mesh_part ? (size_t)a.n_mesh_local : (size_t)a.rt_w * a.rt_h;
+    return std::min(all, ((tiles + 7u) / 8u) * 128u * frames);
+}
+
 StreamPlan stream_plan(const rr_context* ctx, const DispatchDev& a, uint32_t depth)
 {
-    auto rect_wb = [&](uint32_t frames) -> size_t {
-        const size_t all = (size_t)a.blocks_per_frame * frames * 4u;
-        if (a.rt_w == 0u) return all;
-        const size_t groups = ((size_t)a.rt_w * a.rt_h + 7u) / 8u;
-        return std::min(all, groups * 128u * frames);
-    };
+    auto rect_wb = [&](uint32_t frames) -> size_t { return stream_rect_wb(a, frames); };
     auto bytes = [&](uint32_t frames, StreamPlan& pl) -> size_t {
         const size_t wb = rect_wb(frames);
         pl.pixels = wb * 64u;
@@ -850,8 +855,7 @@ int render_stream(rr_context* ctx, const SceneDev& sc, const DispatchDev& a, uin
         if (a.out_f32) b.out_f32 = a.out_f32 + (size_t)f0 * a.frame_stride;
         StreamDev s = ctx->strm;
         s.cap = (uint32_t)ctx->strm_cap;
-        const size_t all = (size_t)b.n_blocks * 4u;
-        s.n_rect_wb = (uint32_t)(a.rt_w == 0u ? all : std::min(all, (((size_t)a.rt_w * a.rt_h + 7u) / 8u) * 128u * fc));
+        s.n_rect_wb = (uint32_t)stream_rect_wb(a, fc);
         RR_HIP(launch_render_stream(sc, b, s, need, pl.n_wg, stats, ctx->stream, ctx->dbg_stream_waves));
     }
     (void)rgb8;
@@ -1009,7 +1013,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     const bool refill_stack16 = ctx->single_identity ? (m0 && m0->n_tris < 32768u && need > 19)
                                                      : (pool_nodes < 32768u && ctx->n_pool_tris + ctx->n_insts < 32768u);
     // ---- the candidates
-    const bool stream_ok = !mesh && !ctx->single_identity && p.max_reflect <= 2 && p.max_refract <= (int)STREAM_MAX_GEN - 2 && refill_stack16 && need <= 39 &&
+    const bool stream_ok = !ctx->single_identity && p.max_reflect <= 2 && p.max_refract <= (int)STREAM_MAX_GEN - 2 && refill_stack16 && need <= 39 &&
                            !a.diag && ctx->dbg_stack == 0 && !ctx->dbg_tlas32;
     const bool paths_ok = !compact && ctx->tile_world == 1 && p.max_reflect <= 2 && need <= 39 && ctx->dbg_stack == 0 && have_rect && depth <= 2;
     auto launch_fused = [&](bool st) -> int {

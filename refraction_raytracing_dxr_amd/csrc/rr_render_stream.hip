@@ -469,7 +469,8 @@ __global__ __launch_bounds__(256) void k_stream_background(SceneDev sc, Dispatch
             const f3 e = env_lookup(sc, D);
             const f3 acc = mk3(fmaf(1.0f, e.x, 0.0f), fmaf(1.0f, e.y, 0.0f), fmaf(1.0f, e.z, 0.0f));
             const size_t o = a.compact_out == 0u ? (size_t)y * a.W + x : (size_t)bp.tile_local * (TILE * TILE) + (bp.py0 + ly) * TILE + (bp.px0 + lx);
-            store_pixel(a, a.out_rgba8 + (size_t)bp.frame * a.frame_stride, a.out_f32 ? a.out_f32 + (size_t)bp.frame * a.frame_stride : nullptr, o, acc);
+            uint32_t* const out = bp.bg ? a.out_bg + (size_t)bp.frame * a.bg_stride : a.out_rgba8 + (size_t)bp.frame * a.frame_stride;
+            store_pixel(a, out, a.out_f32 ? a.out_f32 + (size_t)bp.frame * a.frame_stride : nullptr, o, acc);
         }
     }
     flush_stats<STATS>(a, st, blockIdx.x * 4u + wave, lane);
@@ -500,7 +501,8 @@ __global__ __launch_bounds__(256) void k_stream_resolve(DispatchDev a, StreamDev
         }
     }
     const size_t o = a.compact_out == 0u ? (size_t)y * a.W + x : (size_t)bp.tile_local * (TILE * TILE) + (bp.py0 + ly) * TILE + (bp.px0 + lx);
-    store_pixel(a, a.out_rgba8 + (size_t)bp.frame * a.frame_stride, a.out_f32 ? a.out_f32 + (size_t)bp.frame * a.frame_stride : nullptr, o, acc);
+    uint32_t* const out = bp.bg ? a.out_bg + (size_t)bp.frame * a.bg_stride : a.out_rgba8 + (size_t)bp.frame * a.frame_stride;     // (a group of eight tiles may end in background tiles)
+    store_pixel(a, out, a.out_f32 ? a.out_f32 + (size_t)bp.frame * a.frame_stride : nullptr, o, acc);
 }
 
 // ------------------------------------------------------------------------------------ launcher
@@ -517,6 +519,10 @@ static hipError_t launch_stream_sw(const SceneDev& sc, const DispatchDev& a, con
     if (e != hipSuccess) return e;
     if (s.n_rect_wb < total_wb)
         hipLaunchKernelGGL((k_stream_background<STATS>), dim3((total_wb - s.n_rect_wb + 3u) / 4u), dim3(256), 0, st, sc, a, s);
+    if (s.n_rect_wb == 0u) {        // (a rank without mesh tiles: the background kernel was the whole launch)
+        snprintf(g_stream_name, sizeof g_stream_name, "k_stream_background");
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((k_stream_primary<STACK, STATS, E, WPS>), dim3(n_wg), dim3(256), (size_t)4 * STACK * 64 * sizeof(E), st, sc, a, s);
     // generations that still branch push to the next queue; from count == max_reflect on one kernel follows every chain to its end
     const int chain_gen = a.max_reflect < 1 ? 1 : a.max_reflect;

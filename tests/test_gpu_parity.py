@@ -364,11 +364,12 @@ def test_stream_renderer_renders_the_same_frames(tmp_path):
     followed in place) against the lock-step k_render_fused: every frame byte for byte, float colours bit for bit, the recursion's
     counters equal -- instanced scenes with rotations, non-uniform scales, cull flags and a zero mask, a grid of 100 monkeys,
     Depth 1 / 3 / 9, bounce limits from 0/0 to 12/2 (max_reflect decides which generation the chain kernel starts at), float
-    output, the tone map, and sharded tiles.  Own processes: the switch is read at rr_create."""
+    output, the tone map, sharded tiles (round-robin and the mesh-tile partition, which must also equal the unsharded frames).
+    Own processes: the switch is read at rr_create."""
     import subprocess
     import sys
     code = (
-        "import sys, numpy as np\n"
+        "import os, sys, numpy as np\n"
         "sys.path.insert(0, %r)\n"
         "import refraction_raytracing_dxr_amd as rr\n"
         "from refraction_raytracing_dxr_amd.synth import asset, procedural_env\n"
@@ -405,6 +406,27 @@ def test_stream_renderer_renders_the_same_frames(tmp_path):
         "    cnt += [rays]\n"
         "    r._L.rr_device_free(r._h, gathered)\n"
         "    r.set_tile_partition(0, 1)\n"
+        "    # the mesh-tile partition (rr_mesh_partition), three ranks one after the other on this context, two frames\n"
+        "    F, Wm, Hm, ang = 2, 211, 149, 0.3 + si\n"
+        "    r.set_tile_partition(0, 3); part = r.mesh_partition_for_orbit(Wm, Hm, F, angle=ang)\n"
+        "    fs = max(part.max_mesh_tiles_per_rank, 1) * 3072; bs = max(part.n_bg_tiles, 1) * 3072\n"
+        "    gat, bg, frames = C.c_void_p(), C.c_void_p(), C.c_void_p()\n"
+        "    assert r._L.rr_device_alloc(r._h, 3 * F * fs, C.byref(gat)) == 0 and r._L.rr_device_alloc(r._h, F * bs, C.byref(bg)) == 0\n"
+        "    assert r._L.rr_device_alloc(r._h, F * Wm * Hm * 4, C.byref(frames)) == 0\n"
+        "    for rank in range(3):\n"
+        "        r.set_tile_partition(rank, 3)\n"
+        "        r.render_orbit_mesh_sharded(Wm, Hm, F, C.c_void_p(gat.value + rank * F * fs), fs, bg if rank == 0 else None, bs, angle=ang, params=rr.default_params(max_refract=6))\n"
+        "        r.lane_join(0); r.wait()\n"
+        "        assert r.stats().render_kernel == (7 if os.environ.get('RR_DEBUG_KERNEL') == 'stream' else 0), r.stats().render_kernel\n"
+        "    r.set_tile_partition(0, 3)\n"
+        "    r.assemble_frames_mesh(gat, F * fs, fs, bg, bs, part, F, Wm, Hm, frames, Wm * Hm * 4); r.wait()\n"
+        "    got = np.empty((F, Hm, Wm), np.uint32)\n"
+        "    assert r._L.rr_device_read(r._h, frames, got.ctypes.data_as(C.c_void_p), got.nbytes) == 0\n"
+        "    r.set_tile_partition(0, 1)\n"
+        "    r.render_orbit(Wm, Hm, F, angle=ang, params=rr.default_params(max_refract=6), frames_per_dispatch=F)\n"
+        "    for k in range(F): assert np.array_equal(got[k], r.read_frame(slice=k).view(np.uint32)[..., 0]), ('mesh partition', si, k)\n"
+        "    out += [got[F - 1][:149, :211].astype(np.float64)]\n"
+        "    for b in (gat, bg, frames): r._L.rr_device_free(r._h, b)\n"
         "np.save(sys.argv[1], np.stack(out)); print(' '.join(str(c) for c in cnt))\n") % ROOT
     res = {}
     for k in ("fused", "stream"):
