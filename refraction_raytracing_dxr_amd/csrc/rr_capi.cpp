@@ -180,10 +180,13 @@ struct rr_context {
     std::vector<hipEvent_t> kev;     // pairs
     uint32_t kev_used = 0;
 
-    // k_stream_* (rr_render_stream.hip): ray queues, leaf slots and pixel marks of one pass; grown on demand, never shrunk
-    StreamDev strm = { { nullptr, nullptr }, { nullptr, nullptr }, nullptr, nullptr, nullptr, nullptr, 0, 0 };
-    size_t    strm_cap = 0;          // queue entries allocated (each of the two queues)
-    size_t    strm_pixels = 0;       // pixel ordinals the slots / marks are allocated for
+    // k_stream_* (rr_render_stream.hip): ray queues, leaf slots and pixel marks of one pass; grown on demand, never shrunk.
+    // One set per stream a launch can be on (the lanes, then the context's stream: launches on one stream are ordered, launches
+    // on different lanes overlap), allocated when that stream first renders with the stream renderer.
+    StreamDev strm[MAX_LANES + 1] = {};
+    size_t    strm_cap[MAX_LANES + 1] = {};          // queue entries allocated (each of the two queues)
+    size_t    strm_pixels[MAX_LANES + 1] = {};       // pixel ordinals the slots / marks are allocated for
+    size_t    strm_budget = 0;                       // bytes one set may take (stream_budget)
     // Which of two kernels renders a class of launches is MEASURED, once per scene and launch shape: the scene's first dispatch of
     // a class runs on the default kernel (clocks come up), the second is rendered by both candidates, each bracketed by HIP events
     // (the frames are bit-identical, the dispatch just costs two extra launches), and the faster renders every later one.
@@ -414,7 +417,7 @@ int rr_destroy(rr_context* ctx)
     }
     for (MeshRes& m : ctx->meshes) { dfree(m.d_verts); dfree(m.d_idx); dfree(m.nodes); dfree(m.qnodes); dfree(m.tris); dfree(m.nrms); }
     dfree(ctx->d_env); dfree(ctx->d_insts); dfree(ctx->d_pool_nodes); dfree(ctx->d_pool_qnodes); dfree(ctx->d_pool_tris); dfree(ctx->d_pool_nrms); dfree(ctx->d_rgba8); dfree(ctx->d_f32);
-    dfree(ctx->strm.q[0]); dfree(ctx->strm.q[1]); dfree(ctx->strm.fill[0]); dfree(ctx->strm.fill[1]); dfree(ctx->strm.heads); dfree(ctx->strm.slots); dfree(ctx->strm.pending);
+    for (StreamDev& sd : ctx->strm) { dfree(sd.q[0]); dfree(sd.q[1]); dfree(sd.fill[0]); dfree(sd.fill[1]); dfree(sd.heads); dfree(sd.slots); dfree(sd.pending); }
     for (hipEvent_t e : ctx->ch_ev) if (e) (void)hipEventDestroy(e);
     dfree(ctx->d_assembled); dfree(ctx->d_cnt); dfree(ctx->d_tickets); dfree(ctx->d_screen);
     for (uint32_t l = 0; l <= rr_context::MAX_LANES; ++l) dfree(ctx->d_park[l]); dfree(ctx->d_rays); dfree(ctx->d_hits); dfree(ctx->d_cams);
@@ -774,10 +777,31 @@ inline void mesh_screen_rect(const float box[6], const rr_scene_constants* cams,
 // ---- k_stream_* : buffers and passes ----------------------------------------------------------------------------------
 // One pass renders `fc` consecutive slices of the dispatch.  Worst case per pixel of the ray kernels' blocks: four rays alive in
 // one generation (max_reflect <= 2), so a queue holds 4 x pixels entries plus what the waves' 1 024-entry reservations can
-// leave unused; slots are 64 B and the mark 1 B per pixel.  A pass is sized to stay inside STREAM_BUDGET bytes (288 GB of HBM:
-// the buffers are kept for the life of the context).
-constexpr size_t STREAM_BUDGET = (size_t)12 << 30;
+// leave unused; slots are 64 B and the mark 1 B per pixel.  A pass is sized to stay inside the budget of its buffer set: a sixth
+// of the memory free when the renderer is first used, at most 48 GB -- every kernel of a pass ends in a tail of a few long
+// chains, so passes should be few (the 1 024-instance scene at 2160p, Depth 16: 4.04 / 3.68 / 3.49 / 3.39 ms per frame with
+// 6 / 12 / 24 / 48 GB, i.e. 2 / 4 / 8 / 16 slices per pass).  The buffers are kept for the life of the context.
+constexpr size_t STREAM_BUDGET_MAX = (size_t)48 << 30, STREAM_BUDGET_MIN = (size_t)1 << 30;
 constexpr uint32_t STREAM_BLK = 1024;
+
+size_t stream_budget(rr_context* ctx)
+{
+    if (ctx->strm_budget == 0) {
+        size_t free_b = 0, total_b = 0;
+        size_t b = STREAM_BUDGET_MAX;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) b = std::min(b, free_b / 6u);
+        if (const char* e = getenv("RR_DEBUG_STREAM_BUDGET_GB")) { const long g = atol(e); if (g > 0 && g <= 200) b = (size_t)g << 30; }
+        ctx->strm_budget = std::max(b, STREAM_BUDGET_MIN);
+    }
+    return ctx->strm_budget;
+}
+
+// the buffer set of the stream the dispatch is on
+uint32_t stream_slot(const rr_context* ctx)
+{
+    for (uint32_t l = 0; l < rr_context::MAX_LANES; ++l) if (ctx->lane_stream[l] && ctx->stream == ctx->lane_stream[l]) return l;
+    return rr_context::MAX_LANES;
+}
 
 struct StreamPlan { uint32_t fc, n_wg; size_t cap, pixels; };
 
@@ -791,7 +815,7 @@ size_t stream_rect_wb(const DispatchDev& a, uint32_t frames)
     return std::min(all, ((tiles + 7u) / 8u) * 128u * frames);
 }
 
-StreamPlan stream_plan(const rr_context* ctx, const DispatchDev& a, uint32_t depth)
+StreamPlan stream_plan(rr_context* ctx, const DispatchDev& a, uint32_t depth)
 {
     auto rect_wb = [&](uint32_t frames) -> size_t { return stream_rect_wb(a, frames); };
     auto bytes = [&](uint32_t frames, StreamPlan& pl) -> size_t {
@@ -803,7 +827,8 @@ StreamPlan stream_plan(const rr_context* ctx, const DispatchDev& a, uint32_t dep
     };
     StreamPlan pl{ 1, 1, 0, 0 };
     uint32_t fc = depth;
-    while (fc > 1u && bytes(fc, pl) > STREAM_BUDGET) fc = (fc + 1u) / 2u;
+    const size_t budget = stream_budget(ctx);
+    while (fc > 1u && bytes(fc, pl) > budget) fc = (fc + 1u) / 2u;
     (void)bytes(fc, pl);
     pl.fc = fc;
     return pl;
@@ -812,27 +837,29 @@ StreamPlan stream_plan(const rr_context* ctx, const DispatchDev& a, uint32_t dep
 int ensure_stream_buffers(rr_context* ctx, const StreamPlan& pl)
 {
     if (pl.cap > 0xffffffffull || pl.pixels > 0xffffffffull) return fail(ctx, RR_ERR_UNSUPPORTED, "stream renderer: pass too large for 32-bit ray indices");
-    if (!ctx->strm.heads) {      // head counters and, behind them, the chunk ticket counters: one block, zeroed by one memset per pass
-        RR_HIP(hipMalloc(&ctx->strm.heads, (STREAM_MAX_GEN + STREAM_MAX_GEN * 8u * 16u) * sizeof(uint32_t)));
-        ctx->strm.next = ctx->strm.heads + STREAM_MAX_GEN;
+    const uint32_t slot = stream_slot(ctx);
+    StreamDev& sd = ctx->strm[slot];
+    if (!sd.heads) {      // head counters and, behind them, the chunk ticket counters: one block, zeroed by one memset per pass
+        RR_HIP(hipMalloc(&sd.heads, (STREAM_MAX_GEN + STREAM_MAX_GEN * 8u * 16u) * sizeof(uint32_t)));
+        sd.next = sd.heads + STREAM_MAX_GEN;
     }
-    if (pl.cap > ctx->strm_cap) {
-        RR_HIP(hipDeviceSynchronize());
-        dfree(ctx->strm.q[0]); dfree(ctx->strm.q[1]); dfree(ctx->strm.fill[0]); dfree(ctx->strm.fill[1]);
-        ctx->strm_cap = 0;
+    if (pl.cap > ctx->strm_cap[slot]) {
+        RR_HIP(hipStreamSynchronize(ctx->stream));          // (this stream is the set's only user)
+        dfree(sd.q[0]); dfree(sd.q[1]); dfree(sd.fill[0]); dfree(sd.fill[1]);
+        ctx->strm_cap[slot] = 0;
         for (int k = 0; k < 2; ++k) {
-            RR_HIP(hipMalloc(&ctx->strm.q[k], pl.cap * 48u));
-            RR_HIP(hipMalloc(&ctx->strm.fill[k], (pl.cap / 64u) * 4u));
+            RR_HIP(hipMalloc(&sd.q[k], pl.cap * 48u));
+            RR_HIP(hipMalloc(&sd.fill[k], (pl.cap / 64u) * 4u));
         }
-        ctx->strm_cap = pl.cap;
+        ctx->strm_cap[slot] = pl.cap;
     }
-    if (pl.pixels > ctx->strm_pixels) {
-        RR_HIP(hipDeviceSynchronize());
-        dfree(ctx->strm.slots); dfree(ctx->strm.pending);
-        ctx->strm_pixels = 0;
-        RR_HIP(hipMalloc(&ctx->strm.slots, pl.pixels * 64u));
-        RR_HIP(hipMalloc(&ctx->strm.pending, pl.pixels));
-        ctx->strm_pixels = pl.pixels;
+    if (pl.pixels > ctx->strm_pixels[slot]) {
+        RR_HIP(hipStreamSynchronize(ctx->stream));
+        dfree(sd.slots); dfree(sd.pending);
+        ctx->strm_pixels[slot] = 0;
+        RR_HIP(hipMalloc(&sd.slots, pl.pixels * 64u));
+        RR_HIP(hipMalloc(&sd.pending, pl.pixels));
+        ctx->strm_pixels[slot] = pl.pixels;
     }
     return RR_OK;
 }
@@ -853,8 +880,8 @@ int render_stream(rr_context* ctx, const SceneDev& sc, const DispatchDev& a, uin
         b.n_blocks = a.blocks_per_frame * fc;
         b.out_rgba8 = a.out_rgba8 + (size_t)f0 * a.frame_stride;
         if (a.out_f32) b.out_f32 = a.out_f32 + (size_t)f0 * a.frame_stride;
-        StreamDev s = ctx->strm;
-        s.cap = (uint32_t)ctx->strm_cap;
+        StreamDev s = ctx->strm[stream_slot(ctx)];
+        s.cap = (uint32_t)ctx->strm_cap[stream_slot(ctx)];
         s.n_rect_wb = (uint32_t)stream_rect_wb(a, fc);
         RR_HIP(launch_render_stream(sc, b, s, need, pl.n_wg, stats, ctx->stream, ctx->dbg_stream_waves));
     }

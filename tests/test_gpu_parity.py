@@ -427,6 +427,15 @@ def test_stream_renderer_renders_the_same_frames(tmp_path):
         "    for k in range(F): assert np.array_equal(got[k], r.read_frame(slice=k).view(np.uint32)[..., 0]), ('mesh partition', si, k)\n"
         "    out += [got[F - 1][:149, :211].astype(np.float64)]\n"
         "    for b in (gat, bg, frames): r._L.rr_device_free(r._h, b)\n"
+        "    # launches in flight: every lane has its own queues (seven frames, one per dispatch, three lanes) == one at a time\n"
+        "    r.set_frames_in_flight(3)\n"
+        "    fl = r.render_orbit_to_host(Wm, Hm, 7, angle=ang, params=rr.default_params(max_refract=7), frames_per_dispatch=1).view(np.uint32)[..., 0]\n"
+        "    r.set_frames_in_flight(1)\n"
+        "    aa = np.float32(ang)\n"
+        "    for k in range(7):\n"
+        "        r.render_orbit(Wm, Hm, 1, angle=float(aa), params=rr.default_params(max_refract=7), frames_per_dispatch=1); aa = np.float32(aa + np.float32(0.01))\n"
+        "        assert np.array_equal(fl[k], r.read_frame().view(np.uint32)[..., 0]), ('in flight', si, k)\n"
+        "    out += [fl[6].astype(np.float64)]\n"
         "np.save(sys.argv[1], np.stack(out)); print(' '.join(str(c) for c in cnt))\n") % ROOT
     res = {}
     for k in ("fused", "stream"):
