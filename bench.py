@@ -105,6 +105,29 @@ def pmc_busy_roofs(render_kernel, frames_per_launch):
     return out
 
 
+def pmc_record(tag, must_contain=None, kernel_name=""):
+    """Busy fractions of a kernel from its counter passes under profiles/ (static: a counter pass cannot run inside the bench):
+    vector issue = SQ_ACTIVE_INST_VALU * 4 / SIMD cycles, texture addresser and data return per CU.  None if there is no
+    such file or the kernel that ran is not the one the passes were taken on."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.txt" % tag)))
+    if not cands or (must_contain and must_contain not in kernel_name):
+        return None
+    v = {}
+    for line in open(cands[-1]):
+        f = line.split()
+        if len(f) >= 3 and f[1] == "avg_per_launch":
+            v[f[0]] = float(f[2])
+    try:
+        xcd_cycles = v["GRBM_GUI_ACTIVE"] / 8.0
+        return {"valu_issue_busy": round(v["SQ_ACTIVE_INST_VALU"] * 4.0 / (xcd_cycles * 1024.0), 3),
+                "l1_texture_addresser_busy": round(v["TA_TA_BUSY_sum"] / (xcd_cycles * 256.0), 3),
+                "l1_data_return_busy": round(v["TD_TD_BUSY_sum"] / (xcd_cycles * 256.0), 3),
+                "source": "%s (rocprofv3 --pmc passes of this workload, tools/pmc_passes.sh; static, not measured in this run)" % os.path.relpath(cands[-1], ROOT)}
+    except KeyError:
+        return None
+
+
 def issue_record(st, launches, kernel_us, fused_model_applies):
     """what the vector-issue model says about `launches` launches of `kernel_us` each, from their exact STATS counters"""
     rec = {"kernel": st.render_kernel_name.decode() if isinstance(st.render_kernel_name, bytes) else str(st.render_kernel_name),
@@ -193,6 +216,10 @@ def config_records(r, rr, asset, env):
                 name = r.stats().render_kernel_name
                 rec["roofline"] = issue_record(ss, 1, ms / n * 1e3, fused_model_applies=(inst is None and ss.render_kernel == 0))
                 rec["roofline"]["kernel"] = name.decode() if isinstance(name, bytes) else str(name)
+                if key == "C4":
+                    rec["roofline"]["counters"] = pmc_record("c4_fused", "k_render_fused<39", rec["roofline"]["kernel"])
+                elif key == "C5":
+                    rec["roofline"]["counters"] = pmc_record("c5_stream", "k_stream_rays", rec["roofline"]["kernel"])
         out[key] = rec
     return out
 
@@ -515,6 +542,7 @@ def main():
             subdiv["roofline"]["kernel"] = name16
             subdiv["roofline"]["frames_per_launch"] = F
             subdiv["roofline"]["model_note"] = "per-trip costs fitted on k_render_fused<19, 2, ..., unsigned int>; applied to this instantiation as an estimate"
+            subdiv["roofline"]["counters"] = pmc_record("monkey16k", "k_render_fused<39", name16)
             subdiv["roofline"]["node_visits_per_ray"] = round(ss16.node_visits / ss16.rays, 2)
             subdiv["roofline"]["tri_tests_per_ray"] = round(ss16.tri_tests / ss16.rays, 2)
             r.load_scene(mesh.verts, mesh.indices, env)

@@ -20,8 +20,13 @@ H = int(a[5]) if len(a) > 5 else 1080
 refl = int(a[6]) if len(a) > 6 else 2
 stats = os.environ.get("PROF_STATS") == "1"
 r = rr.Renderer(0)
-m = rr.Mesh(); assert m.load(asset(mesh))
-r.load_scene(m.verts, m.indices, procedural_env(2048, 1024, seed=0))
+m = rr.Mesh(); assert m.load(asset("monkey.obj" if mesh == "monkey16k" else mesh))
+if mesh == "monkey16k":                # BASELINE's "~16k tri Suzanne": monkey.obj midpoint-subdivided twice (15 472 triangles)
+    from refraction_raytracing_dxr_amd.synth import subdivide
+    v16, i16 = subdivide(m.verts, 2)
+    r.load_scene(v16, i16, procedural_env(2048, 1024, seed=0))
+else:
+    r.load_scene(m.verts, m.indices, procedural_env(2048, 1024, seed=0))
 p = rr.default_params(max_refract=refr, max_reflect=refl, flags=rr.DISPATCH_COLLECT_STATS if stats else 0)
 r.render_orbit(W, H, depth * launches, angle=0.01, params=p, frames_per_dispatch=depth)
 r.wait()
