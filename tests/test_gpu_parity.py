@@ -384,7 +384,8 @@ def test_stream_renderer_renders_the_same_frames(tmp_path):
         "r.upload_envmap(procedural_env(256, 128, seed=9))\n"
         "scenes = [rr.make_instances(transforms=[xf(0, 0, 0), xf(0, 0, -2.5, (0.5, 0.8, 0.5), 0.4), xf(0.3, 0.2, 2.4, (0.7, 0.7, 0.7), -1.0), xf(0, 1.9, 0, (0.4, 0.4, 0.4), 0.2), xf(0, -1.8, 0.5, (0.5, 0.5, 0.5))],\n"
         "                            meshes=[ids[1], ids[0], ids[1], ids[2], ids[0]], masks=[1, 1, 0xff, 1, 0], flags=[0, 0, 2, 1, 0]),\n"
-        "          rr.make_instances(transforms=[xf(1.1 * (i - 4.5), 0.3 * ((i + j) %% 3), 1.1 * (j - 4.5), (0.4, 0.4, 0.4), 0.3 * i) for i in range(10) for j in range(10)], meshes=[ids[1]] * 100)]\n"
+        "          rr.make_instances(transforms=[xf(1.1 * (i - 4.5), 0.3 * ((i + j) %% 3), 1.1 * (j - 4.5), (0.4, 0.4, 0.4), 0.3 * i) for i in range(10) for j in range(10)], meshes=[ids[1]] * 100),\n"
+        "          rr.make_instances(transforms=[xf(0.1, 0.05, 0, (0.12, 0.12, 0.12), 0.5), xf(-0.1, 0, 0.1, (0.08, 0.1, 0.08), 2.0)], meshes=[ids[1], ids[2]])]\n"
         "for si, inst in enumerate(scenes):\n"
         "    r.build_tlas(inst)\n"
         "    for depth, frames, kw, extra in ((1, 2, dict(max_refract=8), 0), (3, 3, dict(max_refract=5, max_reflect=1), 0), (9, 9, dict(max_refract=12), rr.DISPATCH_TONEMAP_REINHARD),\n"
@@ -427,6 +428,24 @@ def test_stream_renderer_renders_the_same_frames(tmp_path):
         "    for k in range(F): assert np.array_equal(got[k], r.read_frame(slice=k).view(np.uint32)[..., 0]), ('mesh partition', si, k)\n"
         "    out += [got[F - 1][:149, :211].astype(np.float64)]\n"
         "    for b in (gat, bg, frames): r._L.rr_device_free(r._h, b)\n"
+        "    if si == 2:      # a small scene on eight ranks: rank 0 keeps the background and gets no mesh tile at all\n"
+        "        r.set_tile_partition(0, 8); p8 = r.mesh_partition_for_orbit(320, 200, 1, angle=ang)\n"
+        "        assert p8.rank0_rounds == 0xffffffff and p8.n_mesh_tiles >= 1, (p8.rank0_rounds, p8.n_mesh_tiles, p8.n_bg_tiles)\n"
+        "        fs8 = max(p8.max_mesh_tiles_per_rank, 1) * 3072; bs8 = max(p8.n_bg_tiles, 1) * 3072\n"
+        "        g8, b8, f8 = C.c_void_p(), C.c_void_p(), C.c_void_p()\n"
+        "        assert r._L.rr_device_alloc(r._h, 8 * fs8, C.byref(g8)) == 0 and r._L.rr_device_alloc(r._h, bs8, C.byref(b8)) == 0 and r._L.rr_device_alloc(r._h, 320 * 200 * 4, C.byref(f8)) == 0\n"
+        "        for rank in range(8):\n"
+        "            r.set_tile_partition(rank, 8)\n"
+        "            r.render_orbit_mesh_sharded(320, 200, 1, C.c_void_p(g8.value + rank * fs8), fs8, b8 if rank == 0 else None, bs8, angle=ang, params=rr.default_params(max_refract=6))\n"
+        "            r.lane_join(0); r.wait()\n"
+        "        r.set_tile_partition(0, 8)\n"
+        "        r.assemble_frames_mesh(g8, fs8, fs8, b8, bs8, p8, 1, 320, 200, f8, 320 * 200 * 4); r.wait()\n"
+        "        got8 = np.empty((200, 320), np.uint32)\n"
+        "        assert r._L.rr_device_read(r._h, f8, got8.ctypes.data_as(C.c_void_p), got8.nbytes) == 0\n"
+        "        r.set_tile_partition(0, 1)\n"
+        "        r.render_orbit(320, 200, 1, angle=ang, params=rr.default_params(max_refract=6), frames_per_dispatch=1)\n"
+        "        assert np.array_equal(got8, r.read_frame().view(np.uint32)[..., 0]), 'eight ranks'\n"
+        "        for b in (g8, b8, f8): r._L.rr_device_free(r._h, b)\n"
         "    # launches in flight: every lane has its own queues (seven frames, one per dispatch, three lanes) == one at a time\n"
         "    r.set_frames_in_flight(3)\n"
         "    fl = r.render_orbit_to_host(Wm, Hm, 7, angle=ang, params=rr.default_params(max_refract=7), frames_per_dispatch=1).view(np.uint32)[..., 0]\n"
