@@ -191,17 +191,37 @@ struct rr_context {
     // a class runs on the default kernel (clocks come up), the second is rendered by both candidates, each bracketed by HIP events
     // (the frames are bit-identical, the dispatch just costs two extra launches), and the default renders every later one unless
     // the alternative was more than 3 % faster.
-    // rr_build_tlas and a change of the launch shape (frame size, bounce limits, a rectangle share that doubles or halves) start
-    // the measurement afresh.  Classes: two-level scenes (k_render_fused / k_stream_*), launches of many slices of the
-    // reference's scene (k_render_fused / k_render_lds), launches of one or two slices (k_render_fused / k_render_paths).
+    // rr_build_tlas starts every measurement afresh; a launch shape (frame size, bounce limits, launch depth 1 / 2 / 3-15 / 16-31 /
+    // 32-63 / 64 and up) has its own choice -- a class remembers its four most recent shapes, so a caller that alternates between two
+    // depths does not measure again at every switch -- and a rectangle share that doubles or halves renews a shape's.
+    // Classes: two-level scenes (k_render_fused / k_stream_*), launches of many slices of the reference's scene
+    // (k_render_fused / k_render_lds), launches of one or two slices (k_render_fused / k_render_paths).
     struct KernelChoice {
         int choice = 0;              // 0 undecided, 1 candidate A (k_render_fused), 2 candidate B
         uint32_t seen = 0;
         unsigned long long key = 0;  // the launch shape the choice was measured for
         double share = 0.0;          // rectangle share of the frame at the measurement
         float ms[2] = { 0.0f, 0.0f };
+        bool valid = false;
+        unsigned long long stamp = 0;
     };
-    KernelChoice ch_tlas, ch_many, ch_few;
+    struct ChoiceClass {
+        KernelChoice e[4];
+        unsigned long long clock = 0;
+        KernelChoice* find(unsigned long long key)      // the shape's entry; a new shape takes the place of the least recently used
+        {
+            ++clock;
+            KernelChoice* lru = &e[0];
+            for (KernelChoice& x : e) {
+                if (x.valid && x.key == key) { x.stamp = clock; return &x; }
+                if (x.stamp < lru->stamp) lru = &x;
+            }
+            *lru = KernelChoice();
+            lru->valid = true; lru->key = key; lru->stamp = clock;
+            return lru;
+        }
+    };
+    ChoiceClass ch_tlas, ch_many, ch_few;
     hipEvent_t ch_ev[4] = {};
 
     // trace_rays scratch
@@ -686,7 +706,7 @@ int rr_build_tlas(rr_context* ctx, const rr_instance_desc* instances, uint32_t n
     ctx->single_identity = n == 1 && host[0].identity && (d0.hitgroup_flags >> 24) == 0 && ((d0.instance_id_mask >> 24) & 0xffu) != 0;
     if (scene_stack_need(ctx) > 64) return fail(ctx, RR_ERR_UNSUPPORTED, "rr_build_tlas: TLAS+BLAS deeper than the 64-entry stack");
     ctx->tlas_built = true;
-    ctx->ch_tlas = rr_context::KernelChoice(); ctx->ch_many = rr_context::KernelChoice(); ctx->ch_few = rr_context::KernelChoice();      // a new scene: the kernels are chosen afresh
+    ctx->ch_tlas = rr_context::ChoiceClass(); ctx->ch_many = rr_context::ChoiceClass(); ctx->ch_few = rr_context::ChoiceClass();      // a new scene: the kernels are chosen afresh
     return RR_OK;
 }
 
@@ -1058,14 +1078,13 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         RR_HIP(launch_render_fused(sc, a, !ctx->single_identity && stack16 && ctx->dbg_stack == 0 ? (int)need : stack_sel, p.max_reflect <= 2 ? 2 : 8, st, ctx->stream, stack16));
         return RR_OK;
     };
-    auto launch_lds = [&](bool st) -> int {
-        LdsDispatch q;
-        memset(&q, 0, sizeof q);
-        uint32_t slot = rr_context::MAX_LANES;          // launches on one stream are ordered: one ticket block per stream
-        for (uint32_t l = 0; l < rr_context::MAX_LANES; ++l) if (ctx->lane_stream[l] && ctx->stream == ctx->lane_stream[l]) slot = l;
-        q.tickets = ctx->d_tickets + (size_t)slot * LDS_TICKET_WORDS;
-        q.park_slots = p.max_reflect <= 2 ? 2u : 8u;
-        const size_t park_need = (size_t)ctx->n_cus * 32 * q.park_slots * 8 * 64 * sizeof(uint32_t);     // at most 32 waves per CU
+    // k_render_lds parks reflected rays in a slab per stream slot (allocated at first use: outside anything that is timed)
+    auto lds_slot = [&]() -> uint32_t {
+        for (uint32_t l = 0; l < rr_context::MAX_LANES; ++l) if (ctx->lane_stream[l] && ctx->stream == ctx->lane_stream[l]) return l;
+        return rr_context::MAX_LANES;          // launches on one stream are ordered: one ticket block and one slab per stream
+    };
+    auto ensure_lds_park = [&](uint32_t slot) -> int {
+        const size_t park_need = (size_t)ctx->n_cus * 32 * (p.max_reflect <= 2 ? 2u : 8u) * 8 * 64 * sizeof(uint32_t);     // at most 32 waves per CU
         if (ctx->park_bytes[slot] < park_need) {
             RR_HIP(hipStreamSynchronize(ctx->stream));
             dfree(ctx->d_park[slot]);
@@ -1073,6 +1092,15 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
             RR_HIP(hipMalloc(&ctx->d_park[slot], park_need));
             ctx->park_bytes[slot] = park_need;
         }
+        return RR_OK;
+    };
+    auto launch_lds = [&](bool st) -> int {
+        LdsDispatch q;
+        memset(&q, 0, sizeof q);
+        const uint32_t slot = lds_slot();
+        q.tickets = ctx->d_tickets + (size_t)slot * LDS_TICKET_WORDS;
+        q.park_slots = p.max_reflect <= 2 ? 2u : 8u;
+        if (int r = ensure_lds_park(slot)) return r;
         q.park = ctx->d_park[slot];
         uint32_t rect[4];
         mesh_screen_rect(m0->bounds, ((ctx->dbg_ticket_blocks & 3) == 1 || (p.flags & RR_DISPATCH_DEBUG_NO_CULL)) ? nullptr : h_cams, depth, width, height, rect);
@@ -1096,26 +1124,28 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     // ---- which kernel: forced by RR_DEBUG_KERNEL, or the class's measured choice
     enum { K_FUSED = 0, K_LDS = 1, K_PATHS = 2, K_STREAM = 7 };
     int kernel = K_FUSED;
-    rr_context::KernelChoice* ch = nullptr;             // the class this launch belongs to, if it has two candidates
+    rr_context::ChoiceClass* cls = nullptr;             // the class this launch belongs to, if it has two candidates
     int cand_b = K_FUSED;
     if (ctx->dbg_kernel == 10) { if (stream_ok) kernel = K_STREAM; }
     else if (ctx->dbg_kernel == 5) { if (paths_ok) kernel = K_PATHS; }
     else if (ctx->dbg_kernel == 4) { if (lds_fits && !mesh) kernel = K_LDS; }
     else if (ctx->dbg_kernel == 0 && !a.diag) {
-        if (stream_ok) { ch = &ctx->ch_tlas; cand_b = K_STREAM; }
-        else if (paths_ok) { ch = &ctx->ch_few; cand_b = K_PATHS; }
-        else if (lds_fits && depth >= 3 && !compact && !mesh) { ch = &ctx->ch_many; cand_b = K_LDS; }
+        if (stream_ok) { cls = &ctx->ch_tlas; cand_b = K_STREAM; }
+        else if (paths_ok) { cls = &ctx->ch_few; cand_b = K_PATHS; }
+        else if (lds_fits && depth >= 3 && !compact && !mesh) { cls = &ctx->ch_many; cand_b = K_LDS; }
     }
     if (a.diag && paths_ok && rect_share < 0.25 && ctx->dbg_kernel == 0) kernel = K_PATHS;      // (the diagnostic builds keep round 2's rule)
-    if (ch) {
+    if (cls) {
+        // (k_render_lds gains on k_render_fused with the launch depth: sphere.obj 160 / 160 us per frame at Depth 16, 146 / 157 at 64)
         const unsigned long long key = ((unsigned long long)width << 48) ^ ((unsigned long long)height << 32) ^ ((unsigned long long)(uint32_t)p.max_refract << 8) ^
-                                       ((unsigned long long)(uint32_t)p.max_reflect << 4) ^ (depth <= 2 ? depth : depth < 16 ? 3u : 4u);
-        if (ch->choice != 0 && (ch->key != key || rect_share > 2.0 * ch->share || rect_share * 2.0 < ch->share)) *ch = rr_context::KernelChoice();
+                                       ((unsigned long long)(uint32_t)p.max_reflect << 4) ^ (depth <= 2 ? depth : depth < 16 ? 3u : depth < 32 ? 4u : depth < 64 ? 5u : 6u);
+        rr_context::KernelChoice* const ch = cls->find(key);
+        if (ch->choice != 0 && (rect_share > 2.0 * ch->share || rect_share * 2.0 < ch->share)) { ch->choice = 0; ch->seen = 0; }
         if (ch->choice == 0 && !keep && !(p.flags & RR_DISPATCH_DEBUG_NO_CULL)) {
-            if (ch->key != key) { ch->key = key; ch->seen = 0; }
             if (ch->seen++ >= 1u) {
                 // the measurement: both candidates render this dispatch (product builds), one after the other
                 if (cand_b == K_STREAM) if (int r = ensure_stream_buffers(ctx, stream_plan(ctx, a, depth))) return r;
+                if (cand_b == K_LDS) if (int r = ensure_lds_park(lds_slot())) return r;
                 for (int k = 0; k < 4; ++k) if (!ctx->ch_ev[k]) RR_HIP(hipEventCreate(&ctx->ch_ev[k]));
                 for (int c = 0; c < 2; ++c) {
                     RR_HIP(hipEventRecord(ctx->ch_ev[2 * c], ctx->stream));
