@@ -152,6 +152,7 @@ struct rr_context {
     bool      last_stats = false;
 
     CounterBlock* d_cnt = nullptr;
+    CounterBlock* d_cnt_trial = nullptr;     // what the two renders of a kernel-choice measurement count into (thrown away)
     uint32_t* d_park[MAX_LANES + 1] = {};   // k_render_lds: parked reflected rays, one slab per stream slot like the tickets
     size_t    park_bytes[MAX_LANES + 1] = {};
     // k_render_lds or k_render_fused for launches of many slices?  Neither wins everywhere (sphere.obj / shell.obj 1080p: the LDS
@@ -440,7 +441,7 @@ int rr_destroy(rr_context* ctx)
     dfree(ctx->d_env); dfree(ctx->d_insts); dfree(ctx->d_pool_nodes); dfree(ctx->d_pool_qnodes); dfree(ctx->d_pool_tris); dfree(ctx->d_pool_nrms); dfree(ctx->d_rgba8); dfree(ctx->d_f32);
     for (StreamDev& sd : ctx->strm) { dfree(sd.q[0]); dfree(sd.q[1]); dfree(sd.fill[0]); dfree(sd.fill[1]); dfree(sd.heads); dfree(sd.slots); dfree(sd.pending); }
     for (hipEvent_t e : ctx->ch_ev) if (e) (void)hipEventDestroy(e);
-    dfree(ctx->d_assembled); dfree(ctx->d_cnt); dfree(ctx->d_tickets); dfree(ctx->d_screen);
+    dfree(ctx->d_assembled); dfree(ctx->d_cnt); dfree(ctx->d_cnt_trial); dfree(ctx->d_tickets); dfree(ctx->d_screen);
     for (uint32_t l = 0; l <= rr_context::MAX_LANES; ++l) dfree(ctx->d_park[l]); dfree(ctx->d_rays); dfree(ctx->d_hits); dfree(ctx->d_cams);
     for (int k = 0; k < rr_context::CAM_SLOTS; ++k) { if (ctx->h_cams[k]) (void)hipHostFree(ctx->h_cams[k]); if (ctx->h_cams_ev[k]) (void)hipEventDestroy(ctx->h_cams_ev[k]); }
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -1141,12 +1142,20 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
                                        ((unsigned long long)(uint32_t)p.max_reflect << 4) ^ (depth <= 2 ? depth : depth < 16 ? 3u : depth < 32 ? 4u : depth < 64 ? 5u : 6u);
         rr_context::KernelChoice* const ch = cls->find(key);
         if (ch->choice != 0 && (rect_share > 2.0 * ch->share || rect_share * 2.0 < ch->share)) { ch->choice = 0; ch->seen = 0; }
-        if (ch->choice == 0 && !keep && !(p.flags & RR_DISPATCH_DEBUG_NO_CULL)) {
+        if (ch->choice == 0 && !(p.flags & RR_DISPATCH_DEBUG_NO_CULL)) {
             if (ch->seen++ >= 1u) {
-                // the measurement: both candidates render this dispatch (product builds), one after the other
+                // the measurement: both candidates render this dispatch (product builds), one after the other, counting into a
+                // block of their own (the dispatch's counters are the caller's: a batch of a sharded pipeline keeps adding to them);
+                // launches still running on other lanes would be timed along, so they are waited for first
                 if (cand_b == K_STREAM) if (int r = ensure_stream_buffers(ctx, stream_plan(ctx, a, depth))) return r;
                 if (cand_b == K_LDS) if (int r = ensure_lds_park(lds_slot())) return r;
                 for (int k = 0; k < 4; ++k) if (!ctx->ch_ev[k]) RR_HIP(hipEventCreate(&ctx->ch_ev[k]));
+                if (!ctx->d_cnt_trial) RR_HIP(hipMalloc(&ctx->d_cnt_trial, sizeof(CounterBlock)));
+                RR_HIP(hipDeviceSynchronize());
+                RR_HIP(hipMemsetAsync(ctx->d_cnt_trial, 0, sizeof(CounterBlock), ctx->stream));
+                struct Restore { DispatchDev& a; unsigned long long* c; uint32_t* s; uint32_t* e; ~Restore() { a.counters = c; a.ray_shards = s; a.error_flag = e; } }
+                    restore{ a, a.counters, a.ray_shards, a.error_flag };
+                a.counters = ctx->d_cnt_trial->counters; a.ray_shards = ctx->d_cnt_trial->shards; a.error_flag = &ctx->d_cnt_trial->error;
                 for (int c = 0; c < 2; ++c) {
                     RR_HIP(hipEventRecord(ctx->ch_ev[2 * c], ctx->stream));
                     int r = c == 0 ? launch_fused(false) : cand_b == K_STREAM ? launch_stream(false) : cand_b == K_PATHS ? launch_paths(false) : launch_lds(false);
@@ -1168,7 +1177,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     }
     const bool stream_kernel = kernel == K_STREAM, paths_kernel = kernel == K_PATHS, lds_kernel = kernel == K_LDS;
 
-    if (!keep) RR_HIP(hipMemsetAsync(ctx->d_cnt, 0, sizeof(CounterBlock), ctx->stream));      // (also what a measurement above counted)
+    if (!keep) RR_HIP(hipMemsetAsync(ctx->d_cnt, 0, sizeof(CounterBlock), ctx->stream));
     const bool timed = (p.flags & RR_DISPATCH_TIME_KERNEL) != 0;
     if (timed) {
         if (ctx->kev_used >= 4096) return fail(ctx, RR_ERR_STATE, "dispatch: 4096 timed dispatches pending, call rr_kernel_time");
