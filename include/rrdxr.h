@@ -231,12 +231,14 @@ int  rr_render_orbit_to_host(rr_context* ctx, uint32_t width, uint32_t height, c
                              float* angle, float angle_step, uint32_t n_frames, uint32_t frames_per_dispatch,
                              float fov_y, float aspect, float zn, float zf, uint8_t* host_rgba8);
 
-/* How many launches of rr_render_orbit / rr_render_orbit_sharded may be in flight at once (1..4, default 1 =
- * strictly one after the other, like the reference's fence wait per frame, RefractionDemo.cpp:611).  With 2,
+/* How many launches of rr_render_orbit / rr_render_orbit_sharded may be in flight at once (1..4, default 2;
+ * 1 = strictly one after the other, like the reference's fence wait per frame, RefractionDemo.cpp:611).  With 2,
  * consecutive launches go to two internal streams and write to two output regions, so the few long-running
- * waves that end one launch overlap the start of the next: at frames_per_dispatch = 1 that alone is 1.9x on
- * monkey.obj 1080p.  The call still returns with everything ordered on the context's stream.  Dispatches
- * with RR_DISPATCH_TIME_KERNEL always run one at a time (their durations must be exclusive). */
+ * waves that end one launch overlap the start of the next: monkey.obj 1080p, 137 -> 88 us per frame at
+ * frames_per_dispatch = 4, 87 -> 83 at 16, nothing at 64 (ott.obj: 311 -> 172, 124 -> 107).  The call still returns
+ * with everything ordered on the context's stream.  Dispatches with RR_DISPATCH_TIME_KERNEL always run one at a
+ * time (their durations must be exclusive), and so do launches the persistent k_render_lds was chosen for (its
+ * workgroups hold every CU until the launch ends).  rr_dispatch_rays[_batch] are not affected. */
 int  rr_set_frames_in_flight(rr_context* ctx, uint32_t n);
 
 /* The same loop for a sharded context (rr_set_tile_partition; world == 1 is allowed): frame f renders this rank's tiles straight into

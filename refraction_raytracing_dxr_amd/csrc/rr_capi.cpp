@@ -137,7 +137,7 @@ struct rr_context {
     CamDev*     lane_cams[MAX_LANES] = {};
     size_t      lane_cams_cap[MAX_LANES] = {};
     bool        lane_busy[MAX_LANES] = {};
-    uint32_t    frames_in_flight = 1;    // rr_set_frames_in_flight: launches of rr_render_orbit that may overlap
+    uint32_t    frames_in_flight = 2;    // rr_set_frames_in_flight: launches of rr_render_orbit that may overlap
     size_t      frame_base = 0;          // element offset of the most recent dispatch inside d_rgba8 / d_f32
 
     // frame
@@ -191,7 +191,7 @@ struct rr_context {
     // Which of two kernels renders a class of launches is MEASURED, once per scene and launch shape: the scene's first dispatch of
     // a class runs on the default kernel (clocks come up), the second is rendered by both candidates, each bracketed by HIP events
     // (the frames are bit-identical, the dispatch just costs two extra launches), and the default renders every later one unless
-    // the alternative was more than 3 % faster.
+    // the alternative was more than 5 % faster.
     // rr_build_tlas starts every measurement afresh; a launch shape (frame size, bounce limits, launch depth 1 / 2 / 3-15 / 16-31 /
     // 32-63 / 64 and up) has its own choice -- a class remembers its four most recent shapes, so a caller that alternates between two
     // depths does not measure again at every switch -- and a rectangle share that doubles or halves renews a shape's.
@@ -221,7 +221,17 @@ struct rr_context {
             lru->valid = true; lru->key = key; lru->stamp = clock;
             return lru;
         }
+        const KernelChoice* peek(unsigned long long key) const
+        {
+            for (const KernelChoice& x : e) if (x.valid && x.key == key) return &x;
+            return nullptr;
+        }
     };
+    static unsigned long long choice_key(uint32_t width, uint32_t height, const rr_dispatch_params& p, uint32_t depth)
+    {
+        return ((unsigned long long)width << 48) ^ ((unsigned long long)height << 32) ^ ((unsigned long long)(uint32_t)p.max_refract << 8) ^
+               ((unsigned long long)(uint32_t)p.max_reflect << 4) ^ (depth <= 2 ? depth : depth < 16 ? 3u : depth < 32 ? 4u : depth < 64 ? 5u : 6u);
+    }
     ChoiceClass ch_tlas, ch_many, ch_few;
     hipEvent_t ch_ev[4] = {};
 
@@ -1138,8 +1148,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     if (a.diag && paths_ok && rect_share < 0.25 && ctx->dbg_kernel == 0) kernel = K_PATHS;      // (the diagnostic builds keep round 2's rule)
     if (cls) {
         // (k_render_lds gains on k_render_fused with the launch depth: sphere.obj 160 / 160 us per frame at Depth 16, 146 / 157 at 64)
-        const unsigned long long key = ((unsigned long long)width << 48) ^ ((unsigned long long)height << 32) ^ ((unsigned long long)(uint32_t)p.max_refract << 8) ^
-                                       ((unsigned long long)(uint32_t)p.max_reflect << 4) ^ (depth <= 2 ? depth : depth < 16 ? 3u : depth < 32 ? 4u : depth < 64 ? 5u : 6u);
+        const unsigned long long key = rr_context::choice_key(width, height, p, depth);
         rr_context::KernelChoice* const ch = cls->find(key);
         if (ch->choice != 0 && (rect_share > 2.0 * ch->share || rect_share * 2.0 < ch->share)) { ch->choice = 0; ch->seen = 0; }
         if (ch->choice == 0 && !(p.flags & RR_DISPATCH_DEBUG_NO_CULL)) {
@@ -1165,9 +1174,11 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
                 RR_HIP(hipEventSynchronize(ctx->ch_ev[3]));
                 RR_HIP(hipEventElapsedTime(&ch->ms[0], ctx->ch_ev[0], ctx->ch_ev[1]));
                 RR_HIP(hipEventElapsedTime(&ch->ms[1], ctx->ch_ev[2], ctx->ch_ev[3]));
-                // the alternative has to win by more than one measurement's noise (a launch repeats within 1-2 %): on monkey.obj
-                // k_render_lds and k_render_fused are that close, and a choice that flips from run to run helps nobody
-                ch->choice = ch->ms[1] < 0.97f * ch->ms[0] ? 2 : 1;
+                // the alternative has to win by more than one launch can differ from the orbit's mean: on monkey.obj k_render_lds is
+                // 2 % faster than k_render_fused over the orbit and between 6 % faster and 3 % slower launch by launch
+                // (tools/exp_lds_vs_fused.py; sphere.obj and shell.obj: 6-7 % faster at every angle), and a choice that flips with the
+                // angle the measurement happened at helps nobody
+                ch->choice = ch->ms[1] < 0.95f * ch->ms[0] ? 2 : 1;
                 ch->share = rect_share;
             }
         }
@@ -1364,6 +1375,12 @@ int orbit_impl(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispat
     // one overlap the start of the next.  Not for timed dispatches (their durations must be exclusive).
     uint32_t lanes = ctx->frames_in_flight < n_batches ? ctx->frames_in_flight : n_batches;
     if ((p.flags & RR_DISPATCH_TIME_KERNEL) || !ctx->dbg_diag.empty()) lanes = 1;
+    // k_render_lds is persistent -- its workgroups hold every CU until the launch is over --, so two of its launches in flight only
+    // get in each other's way (sphere.obj Depth 64: 145 us per frame one at a time, 167 with two in flight)
+    if (lanes > 1 && ctx->single_identity) {
+        const rr_context::KernelChoice* c = ctx->ch_many.peek(rr_context::choice_key(width, height, p, batch < n_frames ? batch : n_frames));
+        if ((c && c->choice == 2) || ctx->dbg_kernel == 4) lanes = 1;
+    }
     if (host_out) {          // streaming to host: the copy of one region overlaps the rendering of the other
         if (ext_tiles || ctx->tile_world != 1 || (p.flags & RR_DISPATCH_FLOAT_OUTPUT))
             return fail(ctx, RR_ERR_UNSUPPORTED, "render_orbit_to_host: whole RGBA8 frames of an unsharded context only");

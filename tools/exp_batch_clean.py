@@ -1,10 +1,12 @@
 """frames per launch sweep, best of several passes (the scene's measured kernel choice is made before anything is timed):
-python tools/exp_batch_clean.py [mesh...]"""
+INFLIGHT=<n> python tools/exp_batch_clean.py [mesh...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import refraction_raytracing_dxr_amd as rr
 from refraction_raytracing_dxr_amd.synth import asset, procedural_env
 r = rr.Renderer(0)
+if os.environ.get("INFLIGHT"):
+    r.set_frames_in_flight(int(os.environ["INFLIGHT"]))             # launches of one rr_render_orbit that may overlap (default: the library's, 2)
 for name in (sys.argv[1:] or ["monkey.obj"]):
     m = rr.Mesh(); m.load(asset(name))
     r.load_scene(m.verts, m.indices, procedural_env(2048, 1024, seed=0))
