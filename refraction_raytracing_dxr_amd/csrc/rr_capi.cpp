@@ -190,8 +190,8 @@ struct rr_context {
     size_t    strm_budget = 0;                       // bytes one set may take (stream_budget)
     // Which of two kernels renders a class of launches is MEASURED, once per scene and launch shape: the scene's first dispatch of
     // a class runs on the default kernel (clocks come up), the second is rendered by both candidates, each bracketed by HIP events
-    // (the frames are bit-identical, the dispatch just costs two extra launches), and the default renders every later one unless
-    // the alternative was more than 5 % faster.
+    // (the frames are bit-identical, the dispatch just costs three extra launches), and the default renders every later one unless
+    // the alternative was more than 5 % faster there and on the dispatch after it.
     // rr_build_tlas starts every measurement afresh; a launch shape (frame size, bounce limits, launch depth 1 / 2 / 3-15 / 16-31 /
     // 32-63 / 64 and up) has its own choice -- a class remembers its four most recent shapes, so a caller that alternates between two
     // depths does not measure again at every switch -- and a rectangle share that doubles or halves renews a shape's.
@@ -1150,7 +1150,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         // (k_render_lds gains on k_render_fused with the launch depth: sphere.obj 160 / 160 us per frame at Depth 16, 146 / 157 at 64)
         const unsigned long long key = rr_context::choice_key(width, height, p, depth);
         rr_context::KernelChoice* const ch = cls->find(key);
-        if (ch->choice != 0 && (rect_share > 2.0 * ch->share || rect_share * 2.0 < ch->share)) { ch->choice = 0; ch->seen = 0; }
+        if (ch->choice != 0 && (rect_share > 2.0 * ch->share || rect_share * 2.0 < ch->share)) { ch->choice = 0; ch->seen = 0; ch->ms[0] = ch->ms[1] = 0.0f; }
         if (ch->choice == 0 && !(p.flags & RR_DISPATCH_DEBUG_NO_CULL)) {
             if (ch->seen++ >= 1u) {
                 // the measurement: both candidates render this dispatch (product builds), one after the other, counting into a
@@ -1165,6 +1165,8 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
                 struct Restore { DispatchDev& a; unsigned long long* c; uint32_t* s; uint32_t* e; ~Restore() { a.counters = c; a.ray_shards = s; a.error_flag = e; } }
                     restore{ a, a.counters, a.ray_shards, a.error_flag };
                 a.counters = ctx->d_cnt_trial->counters; a.ray_shards = ctx->d_cnt_trial->shards; a.error_flag = &ctx->d_cnt_trial->error;
+                // A (untimed: the device was just idle, its first launch would pay for the clocks coming back), then A and B timed
+                if (int r = launch_fused(false)) return r;
                 for (int c = 0; c < 2; ++c) {
                     RR_HIP(hipEventRecord(ctx->ch_ev[2 * c], ctx->stream));
                     int r = c == 0 ? launch_fused(false) : cand_b == K_STREAM ? launch_stream(false) : cand_b == K_PATHS ? launch_paths(false) : launch_lds(false);
@@ -1172,13 +1174,17 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
                     RR_HIP(hipEventRecord(ctx->ch_ev[2 * c + 1], ctx->stream));
                 }
                 RR_HIP(hipEventSynchronize(ctx->ch_ev[3]));
-                RR_HIP(hipEventElapsedTime(&ch->ms[0], ctx->ch_ev[0], ctx->ch_ev[1]));
-                RR_HIP(hipEventElapsedTime(&ch->ms[1], ctx->ch_ev[2], ctx->ch_ev[3]));
+                float ms_a = 0.0f, ms_b = 0.0f;
+                RR_HIP(hipEventElapsedTime(&ms_a, ctx->ch_ev[0], ctx->ch_ev[1]));
+                RR_HIP(hipEventElapsedTime(&ms_b, ctx->ch_ev[2], ctx->ch_ev[3]));
                 // the alternative has to win by more than one launch can differ from the orbit's mean: on monkey.obj k_render_lds is
                 // 2 % faster than k_render_fused over the orbit and between 6 % faster and 3 % slower launch by launch
                 // (tools/exp_lds_vs_fused.py; sphere.obj and shell.obj: 6-7 % faster at every angle), and a choice that flips with the
-                // angle the measurement happened at helps nobody
-                ch->choice = ch->ms[1] < 0.95f * ch->ms[0] ? 2 : 1;
+                // angle the measurement happened at helps nobody.  It also has to win TWICE, on consecutive dispatches of the shape.
+                const bool b_wins = ms_b < 0.95f * ms_a;
+                if (!b_wins) { ch->choice = 1; ch->ms[0] = ms_a; ch->ms[1] = ms_b; }
+                else if (ch->ms[1] > 0.0f) { ch->choice = 2; ch->ms[0] = ms_a; ch->ms[1] = ms_b; }         // (ms[] hold the first win until then)
+                else { ch->ms[0] = ms_a; ch->ms[1] = ms_b; }
                 ch->share = rect_share;
             }
         }

@@ -17,9 +17,9 @@ for levels in (0, 2, 3):
         r.build_tlas(rr.make_instances(meshes=[mid]) if ident else rr.make_instances(transforms=[xf], meshes=[mid])); r.upload_envmap(env)
         cams = [rr.camera_orbit(0.01 * (k + 1)) for k in range(F)]
         p = rr.default_params(max_refract=8, flags=rr.DISPATCH_TIME_KERNEL)
-        for rep in range(4):
+        for rep in range(5):
             r.dispatch_rays_batch(W, H, cams, p)
-            if rep == 1: r.kernel_time()
+            if rep == 2: r.kernel_time()
         ms, n = r.kernel_time()
         st = r.stats()
         print("%6d tri %s: %7.1f us/frame %6.2f Grays/s | %s" % (len(i) // 3, "identity" if ident else "shifted ", ms / n * 1e3 / F,
