@@ -52,6 +52,11 @@ VALU_CYCLES_PER_TRIP = {"node": 115.9,      # 30.5 instructions, all quarter rat
                         "pass": 856.4,      # 250.0 per shading pass of a traced wave (ray set-up, ClosestHit / Miss)
                         "wave": 299.6,      # 70.7 per traced 8x8 block: RayGen, addressing, store
                         "bg": 1013.1}       # 280.5 per background block: RayGen, Miss, store
+# k_render_lds (persistent workgroups, nodes in LDS; the measured choice takes it where it is more than 5 % faster: sphere.obj and
+# shell.obj at Depth 64): the same fit on its own counter passes (tools/fit_valu_lds.sh, profiles/r03_valu_fit_lds.txt, eight
+# workloads, residual <= 2.1 %): 29.1 / 72.4 / 226.4 / 75.7 / 282.1 instructions per node trip / leaf trip / pass / block /
+# background block, priced like the others (node trip 29.1 x 3.80; the rest by class).
+VALU_CYCLES_PER_TRIP_LDS = {"node": 110.6, "leaf": 240.9, "pass": 761.5, "wave": 298.7, "bg": 1016.8}
 ROOFLINE_KERNEL = "k_render_fused<19, 2, false, false, false, unsigned int, 0>"
 
 
@@ -70,8 +75,8 @@ def survey_formula_bytes(st):
             + 16 * st.pixels)
 
 
-def valu_issue_cycles(st):
-    c = VALU_CYCLES_PER_TRIP
+def valu_issue_cycles(st, lds=False):
+    c = VALU_CYCLES_PER_TRIP_LDS if lds else VALU_CYCLES_PER_TRIP
     bg = st.background_waves
     return (st.node_trips * c["node"] + st.leaf_trips * c["leaf"] + (st.shade_passes - bg) * c["pass"] + (st.waves - bg) * c["wave"]
             + bg * c["bg"])
@@ -140,7 +145,9 @@ def issue_record(st, launches, kernel_us, fused_model_applies):
                                      "background_waves": int(st.background_waves / launches)},
            "clock_seen_GHz": round(st.clock_ghz, 3) if st.clock_ghz else None}
     if fused_model_applies:
-        cyc = valu_issue_cycles(st) / launches
+        cyc = valu_issue_cycles(st, lds=(st.render_kernel == 1)) / launches
+        if st.render_kernel == 1:
+            rec["model_note"] = "per-trip costs of k_render_lds (profiles/r03_valu_fit_lds.txt)"
         frac = cyc / (kernel_us * 1e-6) / 1e9 / (N_SIMD * CLOCK_GHZ)
         rec["bound"] = "valu_issue"
         rec["frac"] = round(frac, 4) if frac <= 1.0 else None
@@ -214,7 +221,7 @@ def config_records(r, rr, asset, env):
                 ss = r.stats()
                 r.dispatch_rays_batch(W_, H_, cams, rr.default_params(max_refract=refr))      # the product build's name
                 name = r.stats().render_kernel_name
-                rec["roofline"] = issue_record(ss, 1, ms / n * 1e3, fused_model_applies=(inst is None and ss.render_kernel == 0))
+                rec["roofline"] = issue_record(ss, 1, ms / n * 1e3, fused_model_applies=(inst is None and ss.render_kernel in (0, 1)))
                 rec["roofline"]["kernel"] = name.decode() if isinstance(name, bytes) else str(name)
                 if key == "C4":
                     rec["roofline"]["counters"] = pmc_record("c4_fused", "k_render_fused<39", rec["roofline"]["kernel"])
@@ -450,13 +457,14 @@ def main():
                     max_refract=MAX_REFRACT, max_reflect=MAX_REFLECT, flags=rr.DISPATCH_TIME_KERNEL))
                 k1ms, k1n = r.kernel_time()
         # vector-issue roofline: SIMD cycles the launch's wave-level trips need / SIMD cycles the launch had
-        issue_cycles = valu_issue_cycles(sst) / kn
+        issue_cycles = valu_issue_cycles(sst, lds=(render_kernel == 1)) / kn
+        vc = VALU_CYCLES_PER_TRIP_LDS if render_kernel == 1 else VALU_CYCLES_PER_TRIP
         achieved = issue_cycles / (kernel_us * 1e-6) / 1e9                  # G SIMD-cycles of vector issue per second
         peak = N_SIMD * CLOCK_GHZ
         frac = achieved / peak
         model_invalid = None
-        if render_kernel != 0:
-            model_invalid = "the timed launches ran on render kernel %d, which the k_render_fused issue model does not describe" % render_kernel
+        if render_kernel not in (0, 1):
+            model_invalid = "the timed launches ran on render kernel %d, which no issue model describes" % render_kernel
         elif not frac <= 1.0:
             model_invalid = "fitted vector-issue fraction %.3f > 1: the per-trip costs no longer describe the kernel; refit (tools/fit_valu.sh)" % frac
         clock_seen = sst.clock_ghz or None
@@ -483,10 +491,10 @@ def main():
                     "model_invalid": model_invalid,
                     "kernel": kernel_name, "kernel_us": round(kernel_us, 2), "frames_per_launch": Fl,
                     "model": "node_trips*%.1f + leaf_trips*%.1f + (shade_passes - background_waves)*%.1f + (waves - background_waves)*%.1f + "
-                             "background_waves*%.1f SIMD cycles (instruction counts: profiles/r02_valu_fit.txt; cycles per class and the node mix: "
+                             "background_waves*%.1f SIMD cycles (instruction counts: profiles/%s; cycles per class and the node mix: "
                              "profiles/r03_ubench_valu.txt); %d SIMDs x %.1f GHz" % (
-                                 VALU_CYCLES_PER_TRIP["node"], VALU_CYCLES_PER_TRIP["leaf"], VALU_CYCLES_PER_TRIP["pass"],
-                                 VALU_CYCLES_PER_TRIP["wave"], VALU_CYCLES_PER_TRIP["bg"], N_SIMD, CLOCK_GHZ),
+                                 vc["node"], vc["leaf"], vc["pass"], vc["wave"], vc["bg"],
+                                 "r03_valu_fit_lds.txt" if render_kernel == 1 else "r02_valu_fit.txt", N_SIMD, CLOCK_GHZ),
                     "wave_trips_per_launch": {"node": int(sst.node_trips / kn), "leaf": int(sst.leaf_trips / kn),
                                               "shade_passes": int(sst.shade_passes / kn), "waves": int(sst.waves / kn),
                                               "background_waves": int(sst.background_waves / kn)},

@@ -190,8 +190,8 @@ struct rr_context {
     size_t    strm_budget = 0;                       // bytes one set may take (stream_budget)
     // Which of two kernels renders a class of launches is MEASURED, once per scene and launch shape: the scene's first dispatch of
     // a class runs on the default kernel (clocks come up), the second is rendered by both candidates, each bracketed by HIP events
-    // (the frames are bit-identical, the dispatch just costs three extra launches), and the default renders every later one unless
-    // the alternative was more than 5 % faster there and on the dispatch after it.
+    // (the frames are bit-identical, the dispatch just costs three extra launches), and again on the next dispatch of the shape; the default renders every later one unless
+    // the alternative took less than 98 % of its time over the two.
     // rr_build_tlas starts every measurement afresh; a launch shape (frame size, bounce limits, launch depth 1 / 2 / 3-15 / 16-31 /
     // 32-63 / 64 and up) has its own choice -- a class remembers its four most recent shapes, so a caller that alternates between two
     // depths does not measure again at every switch -- and a rectangle share that doubles or halves renews a shape's.
@@ -1139,7 +1139,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     int cand_b = K_FUSED;
     if (ctx->dbg_kernel == 10) { if (stream_ok) kernel = K_STREAM; }
     else if (ctx->dbg_kernel == 5) { if (paths_ok) kernel = K_PATHS; }
-    else if (ctx->dbg_kernel == 4) { if (lds_fits && !mesh) kernel = K_LDS; }
+    else if (ctx->dbg_kernel == 4) { if (lds_fits && !mesh && !compact) kernel = K_LDS; }      // (k_render_lds renders unsharded dispatches only)
     else if (ctx->dbg_kernel == 0 && !a.diag) {
         if (stream_ok) { cls = &ctx->ch_tlas; cand_b = K_STREAM; }
         else if (paths_ok) { cls = &ctx->ch_few; cand_b = K_PATHS; }
@@ -1177,14 +1177,19 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
                 float ms_a = 0.0f, ms_b = 0.0f;
                 RR_HIP(hipEventElapsedTime(&ms_a, ctx->ch_ev[0], ctx->ch_ev[1]));
                 RR_HIP(hipEventElapsedTime(&ms_b, ctx->ch_ev[2], ctx->ch_ev[3]));
-                // the alternative has to win by more than one launch can differ from the orbit's mean: on monkey.obj k_render_lds is
-                // 2 % faster than k_render_fused over the orbit and between 6 % faster and 3 % slower launch by launch
-                // (tools/exp_lds_vs_fused.py; sphere.obj and shell.obj: 6-7 % faster at every angle), and a choice that flips with the
-                // angle the measurement happened at helps nobody.  It also has to win TWICE, on consecutive dispatches of the shape.
-                const bool b_wins = ms_b < 0.95f * ms_a;
-                if (!b_wins) { ch->choice = 1; ch->ms[0] = ms_a; ch->ms[1] = ms_b; }
-                else if (ch->ms[1] > 0.0f) { ch->choice = 2; ch->ms[0] = ms_a; ch->ms[1] = ms_b; }         // (ms[] hold the first win until then)
-                else { ch->ms[0] = ms_a; ch->ms[1] = ms_b; }
+                // Two measurements, on consecutive dispatches of the shape, decide together: the alternative renders the shape from
+                // then on if it took less than 98 % of the default's time over both (a launch repeats within 1-2 %, and how far apart
+                // two kernels are depends on the view: k_render_lds against k_render_fused on monkey.obj at Depth 64 is 2 to 10 %
+                // faster launch by launch round the orbit, 6 % over it; tools/exp_lds_vs_fused.py).  An alternative that is clearly
+                // slower the first time is not measured again.
+                const bool first = !(ch->ms[0] > 0.0f);
+                const float sum_a = ch->ms[0] + ms_a, sum_b = ch->ms[1] + ms_b;
+                if (first && ms_b >= 1.02f * ms_a) ch->choice = 1;
+                else if (!first) ch->choice = sum_b < 0.98f * sum_a ? 2 : 1;
+                ch->ms[0] = sum_a; ch->ms[1] = sum_b;
+                if (getenv("RR_DEBUG_CHOICE"))
+                    fprintf(stderr, "[rr] kernel choice: depth %u candidate %d: default %.3f ms, candidate %.3f ms (%.3f)%s\n", depth, cand_b, ms_a, ms_b,
+                            ms_b / ms_a, ch->choice == 2 ? " -> candidate" : ch->choice == 1 ? " -> default" : " (once more)");
                 ch->share = rect_share;
             }
         }

@@ -285,6 +285,24 @@ __global__ __launch_bounds__(256, TLAS ? 5 : 8) void k_render_paths(SceneDev sc,
 // NW waves per workgroup, WGS workgroups per CU (NW * WGS / 4 waves per SIMD); stack entries are 16 bits (node index or
 // ~leaf index: an LDS-resident array has fewer than 5 120 nodes).  After the last block the last wave to leave
 // zeroes the ticket words, so the next launch on the same slot needs no memset.
+// wave-block wb of an unsharded dispatch (k_render_lds renders nothing else): wave_block_pos without the tile partitions and
+// without the rectangle-first tile order -- this kernel has its own two phases, and every scalar that stays live across the
+// renderer is one that may end up being moved through vector lanes
+__device__ __forceinline__ BlockPos lds_block_pos(const DispatchDev& a, uint32_t wb)
+{
+    BlockPos p;
+    const uint32_t blk = wb >> 2, wave = wb & 3u;
+    p.frame = blk % a.n_frames;
+    uint32_t strip;
+    block_to_tile(blk / a.n_frames, p.tile_local, strip);
+    p.tile_ok = p.tile_local < a.n_local_tiles;
+    p.bg = false;
+    const uint32_t tx = p.tile_local % a.tiles_x, ty = p.tile_local / a.tiles_x;
+    p.px0 = wave * 8u; p.py0 = strip * 8u;
+    p.x0 = tx * TILE + p.px0; p.y0 = ty * TILE + p.py0;
+    return p;
+}
+
 template <int NW, int WGS, bool STATS, bool DIAG = false>
 __global__ __launch_bounds__(NW * 64, NW * WGS / 4) void k_render_lds(SceneDev sc, DispatchDev a, LdsDispatch q)
 {
@@ -321,68 +339,59 @@ __global__ __launch_bounds__(NW * 64, NW * WGS / 4) void k_render_lds(SceneDev s
     const uint32_t NQ = q.n_queues;
     uint32_t home = (blockIdx.x * NW + wave) % NQ;
     if (q.home_xcc) { uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); home = (xcc & 7u) % NQ; }
-    const uint32_t n_chunks = (NQ + 63u) / 64u;
-    uint32_t phase = 0, qi = home;
-    bool stealing = false;
-    unsigned long long left = 0ull;            // other queues of the chunk being looked through that still hold tickets
-    uint32_t chunk = 0, chunks_seen = 0;
-    BlockPos strip;                            // the phase 2 ticket in hand: a 32x8 strip, rendered as four 8x8 blocks
-    uint32_t strip_j = 4u;
+    // Little scalar state on purpose: the renderer below keeps ~70 scalars live, and what does not fit the scalar registers is
+    // moved through vector lanes -- vector instructions (the first form of this loop, which looked through 64 counters at a
+    // time and kept a strip's BlockPos, cost 491 of them in 1 362).
+    uint32_t phase = 0, qi = home, tried = 0;  // tried: queues of this phase the wave has found empty
+    uint32_t strip_u = 0, strip_j = 4u;        // the phase 2 ticket in hand: strip strip_u, rendered as four 8x8 blocks
     for (;;) {
         BlockPos bp;
         bool have = false;
         while (!have) {
             if (strip_j < 4u) {                                 // next block of the strip
-                bp = strip;
-                bp.px0 = strip_j * 8u; bp.x0 = strip.x0 + strip_j * 8u;
+                bp = lds_block_pos(a, strip_u * 4u + strip_j);
                 ++strip_j;
-                have = !in_rect(bp);
+                have = bp.tile_ok && !in_rect(bp);
+                if (!bp.tile_ok) strip_j = 4u;
                 continue;
             }
             if (phase >= 2u) break;
             const uint32_t total = phase == 0u ? q.p1_tickets : q.p2_tickets;
             uint32_t* const cnt = q.tickets + phase * LDS_QUEUES * 16u;
-            if (total != 0u) {
-                const uint32_t n_tickets = total > qi ? (total - qi + NQ - 1u) / NQ : 0u;   // tickets qi, qi + LDS_QUEUES, ...
-                uint32_t t = 0;
-                const unsigned long long dw0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
-                if (lane == 0) t = atomicAdd(&cnt[qi * 16u], 1u);
-                t = __builtin_amdgcn_readfirstlane(t);
-                if (DIAG) { diag_wait += __builtin_amdgcn_s_memtime() - dw0; diag_n += 1ull; }
-                if (t < n_tickets) {
-                    const uint32_t u = qi + NQ * t;
-                    if (phase == 1u) {                          // strip u of the dispatch (wave-blocks 4u .. 4u+3)
-                        strip = wave_block_pos(a, u * 4u);
-                        strip_j = strip.tile_ok ? 0u : 4u;
-                    } else if (q.p1_direct) {                   // slice u % n_frames of rect block u / n_frames
-                        const uint32_t b = u / a.n_frames;
-                        bp.frame = u % a.n_frames; bp.tile_local = 0u; bp.px0 = 0u; bp.py0 = 0u; bp.tile_ok = true;
-                        bp.x0 = q.rx0 + (b % q.rect_bw) * 8u; bp.y0 = q.ry0 + (b / q.rect_bw) * 8u;
-                        have = true;
-                    } else {                                    // wave-block u, if it lies inside the rectangle
-                        bp = wave_block_pos(a, u);
-                        have = bp.tile_ok && in_rect(bp);
-                    }
-                    continue;
+            bool drew = false;
+            uint32_t u = 0;
+            while (total != 0u && tried < NQ) {
+                const uint32_t n_tickets = total > qi ? (total - qi + NQ - 1u) / NQ : 0u;   // tickets qi, qi + NQ, ...
+                // a queue other than the wave's own is looked at before it is drawn from (a counter only ever grows: a queue
+                // seen empty stays empty), so the waves that find everything drained add no atomics to the last ones' wait
+                uint32_t seen = 0u;
+                if (tried != 0u) {
+                    if (lane == 0) seen = __hip_atomic_load(&cnt[qi * 16u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    seen = __builtin_amdgcn_readfirstlane(seen);
                 }
-                // this queue is empty: look through the others, 64 counters at a time, starting behind the wave's own chunk
-                if (!stealing) { stealing = true; chunk = (home / 64u + 1u) % n_chunks; chunks_seen = 0; left = 0ull; }
-                while (left == 0ull && chunks_seen < n_chunks) {
-                    const uint32_t c = chunk * 64u + lane;
-                    const uint32_t seen = c < NQ ? __hip_atomic_load(&cnt[c * 16u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
-                    const uint32_t theirs = total > c ? (total - c + NQ - 1u) / NQ : 0u;
-                    left = __ballot(c < NQ && c != home && seen < theirs);
-                    if (left == 0ull) { chunk = (chunk + 1u) % n_chunks; }
-                    ++chunks_seen;
+                if (seen < n_tickets) {
+                    uint32_t t = 0;
+                    const unsigned long long dw0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
+                    if (lane == 0) t = atomicAdd(&cnt[qi * 16u], 1u);
+                    t = __builtin_amdgcn_readfirstlane(t);
+                    if (DIAG) { diag_wait += __builtin_amdgcn_s_memtime() - dw0; diag_n += 1ull; }
+                    if (t < n_tickets) { u = qi + NQ * t; drew = true; break; }
                 }
-                if (left) {
-                    qi = chunk * 64u + (uint32_t)__ffsll((long long)left) - 1u;
-                    left &= left - 1ull;
-                    if (left == 0ull) chunk = (chunk + 1u) % n_chunks;
-                    continue;
-                }
+                ++tried;
+                qi = qi + 1u == NQ ? 0u : qi + 1u;
             }
-            ++phase; qi = home; stealing = false;
+            if (!drew) { ++phase; qi = home; tried = 0u; continue; }
+            if (phase == 1u) {                                  // strip u of the dispatch (wave-blocks 4u .. 4u+3)
+                strip_u = u; strip_j = 0u;
+            } else if (q.p1_direct) {                           // slice u % n_frames of rect block u / n_frames
+                const uint32_t b = u / a.n_frames;
+                bp.frame = u % a.n_frames; bp.tile_local = 0u; bp.px0 = 0u; bp.py0 = 0u; bp.tile_ok = true; bp.bg = false;
+                bp.x0 = q.rx0 + (b % q.rect_bw) * 8u; bp.y0 = q.ry0 + (b / q.rect_bw) * 8u;
+                have = true;
+            } else {                                            // wave-block u, if it lies inside the rectangle
+                bp = lds_block_pos(a, u);
+                have = bp.tile_ok && in_rect(bp);
+            }
         }
         if (!have) break;
         st.blocks += 1u;
