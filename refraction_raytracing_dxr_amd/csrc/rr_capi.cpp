@@ -1118,7 +1118,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
         // experiments (RR_DEBUG_TICKET): low bits 1 = whole frame in phase 1, 2 = no phase 1, 3 = phase 1 at every depth;
         // +16: eight queues, a wave starts on its XCD's; +32: parked rays in registers
         const int tk = ctx->dbg_ticket_blocks & 3;
-        if (tk == 2 || (depth > 4 && tk != 3 && tk != 1)) rect[2] = rect[0];
+        if (tk == 2) rect[2] = rect[0];
         // eight queues, a wave starts on its XCD's: an XCD then works on every eighth slice, which its L2 rewards
         // (monkey.obj Depth 64: 90 us per frame, 104 with 32 queues entered by wave number)
         q.n_queues = (ctx->dbg_ticket_blocks & 64) ? 64u : (ctx->dbg_ticket_blocks & 128) ? LDS_QUEUES : 8u;   // launch_render_lds caps it at the grid size

@@ -285,21 +285,33 @@ __global__ __launch_bounds__(256, TLAS ? 5 : 8) void k_render_paths(SceneDev sc,
 // NW waves per workgroup, WGS workgroups per CU (NW * WGS / 4 waves per SIMD); stack entries are 16 bits (node index or
 // ~leaf index: an LDS-resident array has fewer than 5 120 nodes).  After the last block the last wave to leave
 // zeroes the ticket words, so the next launch on the same slot needs no memset.
-// wave-block wb of an unsharded dispatch (k_render_lds renders nothing else): wave_block_pos without the tile partitions and
-// without the rectangle-first tile order -- this kernel has its own two phases, and every scalar that stays live across the
-// renderer is one that may end up being moved through vector lanes
-__device__ __forceinline__ BlockPos lds_block_pos(const DispatchDev& a, uint32_t wb)
+// k_render_lds renders unsharded dispatches only, and its blocks come from its own two phases: no tile partitions, no launch
+// order of tiles -- every scalar that stays live across the renderer is one that may end up being moved through vector lanes.
+// block j (0..15, row-major 8x8 blocks) of phase 2 ticket u = tile * n_frames + slice
+__device__ __forceinline__ BlockPos lds_tile_block(const DispatchDev& a, uint32_t u, uint32_t j)
 {
     BlockPos p;
-    const uint32_t blk = wb >> 2, wave = wb & 3u;
-    p.frame = blk % a.n_frames;
-    uint32_t strip;
-    block_to_tile(blk / a.n_frames, p.tile_local, strip);
-    p.tile_ok = p.tile_local < a.n_local_tiles;
+    const uint32_t tile = u / a.n_frames;
+    p.frame = u - tile * a.n_frames;
+    p.tile_local = tile;
+    p.tile_ok = tile < a.n_local_tiles;
     p.bg = false;
-    const uint32_t tx = p.tile_local % a.tiles_x, ty = p.tile_local / a.tiles_x;
-    p.px0 = wave * 8u; p.py0 = strip * 8u;
+    const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    p.px0 = (j & 3u) * 8u; p.py0 = (j >> 2) * 8u;
     p.x0 = tx * TILE + p.px0; p.y0 = ty * TILE + p.py0;
+    return p;
+}
+
+// block j (0..3) of phase 1 ticket u = strip * n_frames + slice: strip = a 32x8 run of the scene's screen rectangle, row-major
+__device__ __forceinline__ BlockPos lds_rect_block(const DispatchDev& a, const LdsDispatch& q, uint32_t u, uint32_t j)
+{
+    BlockPos p;
+    const uint32_t strip = u / a.n_frames, per_row = q.rect_bw >> 2;
+    p.frame = u - strip * a.n_frames;
+    const uint32_t row = strip / per_row, col = strip - row * per_row;
+    p.tile_local = 0u; p.tile_ok = true; p.bg = false;
+    p.px0 = 0u; p.py0 = 0u;
+    p.x0 = q.rx0 + col * 32u + j * 8u; p.y0 = q.ry0 + row * 8u;
     return p;
 }
 
@@ -309,7 +321,9 @@ __global__ __launch_bounds__(NW * 64, NW * WGS / 4) void k_render_lds(SceneDev s
     typedef uint16_t E;
     __shared__ uint32_t diag_tr[3 * 16];        // diagnostic builds: per wave internal trips, leaf trips, shading passes
     __shared__ uint32_t wg_arrived;             // waves of this workgroup that have finished
+    __shared__ unsigned long long wg_share[16]; // per wave: ((ticket + 1) | tile << 31) << 32 | next block of the ticket it drew that is still to be rendered
     if (threadIdx.x == 0) wg_arrived = 0u;      // (ordered before its first use by the barrier behind the node copy)
+    if (threadIdx.x < 16) wg_share[threadIdx.x] = 0ull;
     const unsigned long long diag_t0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long diag_wait = 0ull, diag_render = 0ull, diag_n = 0ull;       // cycles in ticket draws / in blocks, tickets | blocks << 32
     unsigned long long diag_worst = 0ull, diag_worst_trips = 0ull;                // the wave's longest block: cycles, its trips (I | L << 20 | S << 40)
@@ -343,17 +357,37 @@ __global__ __launch_bounds__(NW * 64, NW * WGS / 4) void k_render_lds(SceneDev s
     // moved through vector lanes -- vector instructions (the first form of this loop, which looked through 64 counters at a
     // time and kept a strip's BlockPos, cost 491 of them in 1 362).
     uint32_t phase = 0, qi = home, tried = 0;  // tried: queues of this phase the wave has found empty
-    uint32_t strip_u = 0, strip_j = 4u;        // the phase 2 ticket in hand: strip strip_u, rendered as four 8x8 blocks
     for (;;) {
         BlockPos bp;
         bool have = false;
         while (!have) {
-            if (strip_j < 4u) {                                 // next block of the strip
-                bp = lds_block_pos(a, strip_u * 4u + strip_j);
-                ++strip_j;
-                have = bp.tile_ok && !in_rect(bp);
-                if (!bp.tile_ok) strip_j = 4u;
-                continue;
+            // A ticket is several blocks next to each other, which share triangles and texels in the CU's L1: a 32x8 strip of the
+            // scene's screen rectangle in phase 1, a whole 32x32 tile of what lies outside it in phase 2 (the background costs a
+            // microsecond per block: eight counters hand out ~600 tickets per microsecond, and tickets of four blocks had the
+            // background phases ask for twice that).  One wave rendering a ticket's blocks one after the other would be a chain
+            // that many blocks long, and a launch cannot end before its longest chain has (1 ms on monkey.obj, on top of every
+            // launch, when this kernel did that).  So the wave that draws a ticket keeps its first block and leaves the others in
+            // its slot of wg_share for whichever wave of the workgroup needs a block next -- its own slot first, then the others':
+            // one LDS read of all slots, one LDS atomic.
+            {
+                uint32_t got = 0xffffffffu, got_u = 0u;
+                for (;;) {                                      // (again only after losing a block to another wave)
+                    const unsigned long long mine = lane < (uint32_t)NW ? wg_share[lane] : 0ull;      // every slot at once, one per lane
+                    const uint32_t mh = (uint32_t)(mine >> 32);
+                    const unsigned long long m = __ballot(mh != 0u && (uint32_t)mine < ((mh & 0x80000000u) ? 16u : 4u));
+                    if (m == 0ull) break;
+                    const unsigned long long from_own = m >> wave << wave;                       // the wave's own slot first, then the next ones
+                    const uint32_t sl = (uint32_t)__ffsll((long long)(from_own ? from_own : m)) - 1u;
+                    unsigned long long v = 0ull;
+                    if (lane == 0) v = atomicAdd(&wg_share[sl], 1ull);
+                    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+                    if (hi != 0u && lo < ((hi & 0x80000000u) ? 16u : 4u)) { got = lo; got_u = hi; break; }
+                }
+                if (got != 0xffffffffu) {
+                    if (got_u & 0x80000000u) { bp = lds_tile_block(a, (got_u & 0x7fffffffu) - 1u, got); have = bp.tile_ok && !in_rect(bp); }
+                    else { bp = lds_rect_block(a, q, got_u - 1u, got); have = true; }
+                    continue;
+                }
             }
             if (phase >= 2u) break;
             const uint32_t total = phase == 0u ? q.p1_tickets : q.p2_tickets;
@@ -381,16 +415,15 @@ __global__ __launch_bounds__(NW * 64, NW * WGS / 4) void k_render_lds(SceneDev s
                 qi = qi + 1u == NQ ? 0u : qi + 1u;
             }
             if (!drew) { ++phase; qi = home; tried = 0u; continue; }
-            if (phase == 1u) {                                  // strip u of the dispatch (wave-blocks 4u .. 4u+3)
-                strip_u = u; strip_j = 0u;
-            } else if (q.p1_direct) {                           // slice u % n_frames of rect block u / n_frames
-                const uint32_t b = u / a.n_frames;
-                bp.frame = u % a.n_frames; bp.tile_local = 0u; bp.px0 = 0u; bp.py0 = 0u; bp.tile_ok = true; bp.bg = false;
-                bp.x0 = q.rx0 + (b % q.rect_bw) * 8u; bp.y0 = q.ry0 + (b / q.rect_bw) * 8u;
+            // block 0 of the ticket is this wave's, the rest is for the workgroup
+            if (phase == 0u) {
+                if (lane == 0) wg_share[wave] = ((unsigned long long)(u + 1u) << 32) | 1ull;
+                bp = lds_rect_block(a, q, u, 0u);
                 have = true;
-            } else {                                            // wave-block u, if it lies inside the rectangle
-                bp = lds_block_pos(a, u);
-                have = bp.tile_ok && in_rect(bp);
+            } else {
+                if (lane == 0) wg_share[wave] = ((unsigned long long)((u + 1u) | 0x80000000u) << 32) | 1ull;
+                bp = lds_tile_block(a, u, 0u);
+                have = bp.tile_ok && !in_rect(bp);
             }
         }
         if (!have) break;
@@ -666,11 +699,16 @@ hipError_t launch_render_lds(const SceneDev& sc, const DispatchDev& a, LdsDispat
         if (q.n_queues < 1u) q.n_queues = 1u;
     }
     q.p2_strips = 1u;
-    q.p2_tickets = a.n_blocks;                  // one 32x8 strip (four wave-blocks) per ticket
+    q.p2_tickets = a.n_local_tiles * a.n_frames;        // phase 2: one 32x32 tile of one slice per ticket (blocks inside the rectangle are skipped)
+    // phase 1: the rectangle, widened to whole 32-pixel columns, in 32x8 strips of one slice each
+    if (q.rx1 > q.rx0 && q.ry1 > q.ry0) {
+        q.rx0 &= ~31u;
+        q.rx1 = (q.rx1 + 31u) & ~31u;
+    }
     const bool rect = q.rx1 > q.rx0 && q.ry1 > q.ry0;
     q.rect_bw = rect ? (q.rx1 - q.rx0) / 8u : 0u;
-    q.p1_direct = (a.compact_out == 0u && a.tile_world == 1u) ? 1u : 0u;
-    q.p1_tickets = !rect ? 0u : q.p1_direct ? q.rect_bw * ((q.ry1 - q.ry0) / 8u) * a.n_frames : q.wave_blocks;
+    q.p1_direct = 1u;
+    q.p1_tickets = !rect ? 0u : (q.rect_bw / 4u) * ((q.ry1 - q.ry0) / 8u) * a.n_frames;
     if (a.diag) {       // diagnostic build (RR_DEBUG_DIAG): per-wave cycles in ticket draws and in blocks; 12x2 shape
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_lds<12, 2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
         if (attr != hipSuccess) return attr;
