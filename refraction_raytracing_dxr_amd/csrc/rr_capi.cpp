@@ -1053,7 +1053,8 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     // k_render_lds (persistent workgroups, the BLAS's nodes in LDS) is an alternative for the reference's small meshes that
     // measures within 1-3 % of k_render_fused either way (monkey.obj Depth 64: 5.71 against 5.68 ms per launch); it is kept
     // behind RR_DEBUG_KERNEL=lds, for the parity tests and for experiments, and never chosen by itself.
-    const bool lds_fits = m0 && ctx->dbg_stack == 0 && m0->n_tris < 32768u && lds_kernel_shape(node_bytes, need + 1, nullptr, ctx->dbg_shape) >= 0;
+    const bool lds_fits = m0 && ctx->dbg_stack == 0 && m0->n_tris < 32768u && lds_kernel_shape(node_bytes, need + 1, nullptr, ctx->dbg_shape) >= 0 &&
+                          (uint64_t)a.n_tiles * depth * depth < 0x40000000ull;       // (its ticket arithmetic divides by multiply-high)
     // Launches of one or two slices whose scene is small on screen last as long as their most expensive wave: there the
     // path-parallel kernel (four lanes per pixel inside the scene's screen rectangle: a fifth of the longest chain of
     // dependent rays, four waves per block) wins -- monkey.obj 1080p Depth 1: 268 us against 471, ott.obj 626 against 1 419.

@@ -288,15 +288,17 @@ __global__ __launch_bounds__(256, TLAS ? 5 : 8) void k_render_paths(SceneDev sc,
 // k_render_lds renders unsharded dispatches only, and its blocks come from its own two phases: no tile partitions, no launch
 // order of tiles -- every scalar that stays live across the renderer is one that may end up being moved through vector lanes.
 // block j (0..15, row-major 8x8 blocks) of phase 2 ticket u = tile * n_frames + slice
-__device__ __forceinline__ BlockPos lds_tile_block(const DispatchDev& a, uint32_t u, uint32_t j)
+// (divisions by launch constants are a multiply-high with a reciprocal from the host: a scalar division would be done in the
+// vector unit, twenty-odd instructions each)
+__device__ __forceinline__ BlockPos lds_tile_block(const DispatchDev& a, const LdsDispatch& q, uint32_t u, uint32_t j)
 {
     BlockPos p;
-    const uint32_t tile = u / a.n_frames;
+    const uint32_t tile = a.n_frames == 1u ? u : __umulhi(u, q.div_frames);
     p.frame = u - tile * a.n_frames;
     p.tile_local = tile;
     p.tile_ok = tile < a.n_local_tiles;
     p.bg = false;
-    const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const uint32_t ty = a.tiles_x == 1u ? tile : __umulhi(tile, q.div_tiles_x), tx = tile - ty * a.tiles_x;
     p.px0 = (j & 3u) * 8u; p.py0 = (j >> 2) * 8u;
     p.x0 = tx * TILE + p.px0; p.y0 = ty * TILE + p.py0;
     return p;
@@ -306,9 +308,9 @@ __device__ __forceinline__ BlockPos lds_tile_block(const DispatchDev& a, uint32_
 __device__ __forceinline__ BlockPos lds_rect_block(const DispatchDev& a, const LdsDispatch& q, uint32_t u, uint32_t j)
 {
     BlockPos p;
-    const uint32_t strip = u / a.n_frames, per_row = q.rect_bw >> 2;
+    const uint32_t strip = a.n_frames == 1u ? u : __umulhi(u, q.div_frames), per_row = q.rect_bw >> 2;
     p.frame = u - strip * a.n_frames;
-    const uint32_t row = strip / per_row, col = strip - row * per_row;
+    const uint32_t row = per_row == 1u ? strip : __umulhi(strip, q.div_per_row), col = strip - row * per_row;
     p.tile_local = 0u; p.tile_ok = true; p.bg = false;
     p.px0 = 0u; p.py0 = 0u;
     p.x0 = q.rx0 + col * 32u + j * 8u; p.y0 = q.ry0 + row * 8u;
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(NW * 64, NW * WGS / 4) void k_render_lds(SceneDev s
                     if (hi != 0u && lo < ((hi & 0x80000000u) ? 16u : 4u)) { got = lo; got_u = hi; break; }
                 }
                 if (got != 0xffffffffu) {
-                    if (got_u & 0x80000000u) { bp = lds_tile_block(a, (got_u & 0x7fffffffu) - 1u, got); have = bp.tile_ok && !in_rect(bp); }
+                    if (got_u & 0x80000000u) { bp = lds_tile_block(a, q, (got_u & 0x7fffffffu) - 1u, got); have = bp.tile_ok && !in_rect(bp); }
                     else { bp = lds_rect_block(a, q, got_u - 1u, got); have = true; }
                     continue;
                 }
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(NW * 64, NW * WGS / 4) void k_render_lds(SceneDev s
                 have = true;
             } else {
                 if (lane == 0) wg_share[wave] = ((unsigned long long)((u + 1u) | 0x80000000u) << 32) | 1ull;
-                bp = lds_tile_block(a, u, 0u);
+                bp = lds_tile_block(a, q, u, 0u);
                 have = bp.tile_ok && !in_rect(bp);
             }
         }
@@ -709,6 +711,10 @@ hipError_t launch_render_lds(const SceneDev& sc, const DispatchDev& a, LdsDispat
     q.rect_bw = rect ? (q.rx1 - q.rx0) / 8u : 0u;
     q.p1_direct = 1u;
     q.p1_tickets = !rect ? 0u : (q.rect_bw / 4u) * ((q.ry1 - q.ry0) / 8u) * a.n_frames;
+    if ((uint64_t)q.p2_tickets * a.n_frames >= 0xffffffffull || (uint64_t)q.p1_tickets * a.n_frames >= 0xffffffffull) return hipErrorInvalidValue;   // (multiply-high divisions)
+    q.div_frames = (uint32_t)(0x100000000ull / a.n_frames) + 1u;
+    q.div_tiles_x = (uint32_t)(0x100000000ull / a.tiles_x) + 1u;
+    q.div_per_row = rect ? (uint32_t)(0x100000000ull / (q.rect_bw / 4u)) + 1u : 0u;
     if (a.diag) {       // diagnostic build (RR_DEBUG_DIAG): per-wave cycles in ticket draws and in blocks; 12x2 shape
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_lds<12, 2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
         if (attr != hipSuccess) return attr;

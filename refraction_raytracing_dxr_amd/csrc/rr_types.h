@@ -165,6 +165,7 @@ struct LdsDispatch {
     uint32_t park_slots;        // >= max_reflect
     uint32_t node_bytes;        // size of the node array copied to LDS (multiple of 32)
     uint32_t stack_entries;     // per-lane traversal stack entries (> tree depth)
+    uint32_t div_frames, div_tiles_x, div_per_row;   // 2^32 / d + 1 for d = n_frames, tiles_x, strips per rectangle row: x / d == umulhi(x, div) for x * d < 2^32
 };
 // Ticket counters: ticket u belongs to queue u % n_queues; a wave starts on the queue of its XCD's number and, once that
 // is empty, looks through the other counters 64 at a time (plain loads past the L1: a counter only ever grows, so a queue
