@@ -192,8 +192,8 @@ struct rr_context {
     // a class runs on the default kernel (clocks come up), the second is rendered by both candidates, each bracketed by HIP events
     // (the frames are bit-identical, the dispatch just costs three extra launches), and again on the next dispatch of the shape; the default renders every later one unless
     // the alternative took less than 98 % of its time over the two.
-    // rr_build_tlas starts every measurement afresh; a launch shape (frame size, bounce limits, launch depth 1 / 2 / 3-15 / 16-31 /
-    // 32-63 / 64 and up) has its own choice -- a class remembers its four most recent shapes, so a caller that alternates between two
+    // rr_build_tlas starts every measurement afresh; a launch shape (frame size, bounce limits, launch depth 1 / 2 / 3-7 / 8-23 /
+    // 24-47 / 48 and up) has its own choice -- a class remembers its four most recent shapes, so a caller that alternates between two
     // depths does not measure again at every switch -- and a rectangle share that doubles or halves renews a shape's.
     // Classes: two-level scenes (k_render_fused / k_stream_*), launches of many slices of the reference's scene
     // (k_render_fused / k_render_lds), launches of one or two slices (k_render_fused / k_render_paths).
@@ -230,7 +230,7 @@ struct rr_context {
     static unsigned long long choice_key(uint32_t width, uint32_t height, const rr_dispatch_params& p, uint32_t depth)
     {
         return ((unsigned long long)width << 48) ^ ((unsigned long long)height << 32) ^ ((unsigned long long)(uint32_t)p.max_refract << 8) ^
-               ((unsigned long long)(uint32_t)p.max_reflect << 4) ^ (depth <= 2 ? depth : depth < 16 ? 3u : depth < 32 ? 4u : depth < 64 ? 5u : 6u);
+               ((unsigned long long)(uint32_t)p.max_reflect << 4) ^ (depth <= 2 ? depth : depth < 8 ? 3u : depth < 24 ? 4u : depth < 48 ? 5u : 6u);
     }
     ChoiceClass ch_tlas, ch_many, ch_few;
     hipEvent_t ch_ev[4] = {};
@@ -828,6 +828,18 @@ size_t stream_budget(rr_context* ctx)
     return ctx->strm_budget;
 }
 
+// launches of the reference's scene from this many slices on take k_render_lds unless k_render_fused measures faster
+inline bool lds_default_depth(uint32_t depth) { return depth >= 24u; }
+
+// the reference's scene (one identity instance) with a node array small enough for LDS beside the traversal stacks
+bool scene_fits_lds(const rr_context* ctx)
+{
+    if (!ctx->single_identity || ctx->dbg_stack != 0 || ctx->inst_host.empty()) return false;
+    const MeshRes& m0 = ctx->meshes[(size_t)ctx->inst_host[0].blas];
+    const uint32_t node_bytes = (m0.n_tris > 1 ? m0.n_tris - 1 : 1) * (uint32_t)sizeof(QNode);
+    return m0.n_tris < 32768u && lds_kernel_shape(node_bytes, scene_stack_need(ctx) + 1, nullptr, ctx->dbg_shape) >= 0;
+}
+
 // the buffer set of the stream the dispatch is on
 uint32_t stream_slot(const rr_context* ctx)
 {
@@ -1053,8 +1065,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     // k_render_lds (persistent workgroups, the BLAS's nodes in LDS) is an alternative for the reference's small meshes that
     // measures within 1-3 % of k_render_fused either way (monkey.obj Depth 64: 5.71 against 5.68 ms per launch); it is kept
     // behind RR_DEBUG_KERNEL=lds, for the parity tests and for experiments, and never chosen by itself.
-    const bool lds_fits = m0 && ctx->dbg_stack == 0 && m0->n_tris < 32768u && lds_kernel_shape(node_bytes, need + 1, nullptr, ctx->dbg_shape) >= 0 &&
-                          (uint64_t)a.n_tiles * depth * depth < 0x40000000ull;       // (its ticket arithmetic divides by multiply-high)
+    const bool lds_fits = scene_fits_lds(ctx) && (uint64_t)a.n_tiles * depth * depth < 0x40000000ull;       // (its ticket arithmetic divides by multiply-high)
     // Launches of one or two slices whose scene is small on screen last as long as their most expensive wave: there the
     // path-parallel kernel (four lanes per pixel inside the scene's screen rectangle: a fifth of the longest chain of
     // dependent rays, four waves per block) wins -- monkey.obj 1080p Depth 1: 268 us against 471, ott.obj 626 against 1 419.
@@ -1137,14 +1148,20 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
     enum { K_FUSED = 0, K_LDS = 1, K_PATHS = 2, K_STREAM = 7 };
     int kernel = K_FUSED;
     rr_context::ChoiceClass* cls = nullptr;             // the class this launch belongs to, if it has two candidates
-    int cand_b = K_FUSED;
+    int cand_a = K_FUSED, cand_b = K_FUSED;          // the default and the alternative of the launch's class
     if (ctx->dbg_kernel == 10) { if (stream_ok) kernel = K_STREAM; }
     else if (ctx->dbg_kernel == 5) { if (paths_ok) kernel = K_PATHS; }
     else if (ctx->dbg_kernel == 4) { if (lds_fits && !mesh && !compact) kernel = K_LDS; }      // (k_render_lds renders unsharded dispatches only)
     else if (ctx->dbg_kernel == 0 && !a.diag) {
         if (stream_ok) { cls = &ctx->ch_tlas; cand_b = K_STREAM; }
         else if (paths_ok) { cls = &ctx->ch_few; cand_b = K_PATHS; }
-        else if (lds_fits && depth >= 3 && !compact && !mesh) { cls = &ctx->ch_many; cand_b = K_LDS; }
+        else if (lds_fits && depth >= 3 && !compact && !mesh) {
+            // the persistent kernel pays off from about twenty slices a launch (monkey.obj: 1.43 against 1.38 ms at Depth 16,
+            // 1.67 / 1.74 at 20, 2.53 / 2.77 at 32, 4.80 / 5.45 at 64; tools/exp_lds_depths.py): from 24 on it is the default, the
+            // L1-fed one the alternative
+            cls = &ctx->ch_many;
+            if (lds_default_depth(depth)) { cand_a = K_LDS; cand_b = K_FUSED; } else cand_b = K_LDS;
+        }
     }
     if (a.diag && paths_ok && rect_share < 0.25 && ctx->dbg_kernel == 0) kernel = K_PATHS;      // (the diagnostic builds keep round 2's rule)
     if (cls) {
@@ -1158,7 +1175,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
                 // block of their own (the dispatch's counters are the caller's: a batch of a sharded pipeline keeps adding to them);
                 // launches still running on other lanes would be timed along, so they are waited for first
                 if (cand_b == K_STREAM) if (int r = ensure_stream_buffers(ctx, stream_plan(ctx, a, depth))) return r;
-                if (cand_b == K_LDS) if (int r = ensure_lds_park(lds_slot())) return r;
+                if (cand_a == K_LDS || cand_b == K_LDS) if (int r = ensure_lds_park(lds_slot())) return r;
                 for (int k = 0; k < 4; ++k) if (!ctx->ch_ev[k]) RR_HIP(hipEventCreate(&ctx->ch_ev[k]));
                 if (!ctx->d_cnt_trial) RR_HIP(hipMalloc(&ctx->d_cnt_trial, sizeof(CounterBlock)));
                 RR_HIP(hipDeviceSynchronize());
@@ -1167,11 +1184,11 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
                     restore{ a, a.counters, a.ray_shards, a.error_flag };
                 a.counters = ctx->d_cnt_trial->counters; a.ray_shards = ctx->d_cnt_trial->shards; a.error_flag = &ctx->d_cnt_trial->error;
                 // A (untimed: the device was just idle, its first launch would pay for the clocks coming back), then A and B timed
-                if (int r = launch_fused(false)) return r;
+                auto launch_k = [&](int k) -> int { return k == K_STREAM ? launch_stream(false) : k == K_PATHS ? launch_paths(false) : k == K_LDS ? launch_lds(false) : launch_fused(false); };
+                if (int r = launch_k(cand_a)) return r;
                 for (int c = 0; c < 2; ++c) {
                     RR_HIP(hipEventRecord(ctx->ch_ev[2 * c], ctx->stream));
-                    int r = c == 0 ? launch_fused(false) : cand_b == K_STREAM ? launch_stream(false) : cand_b == K_PATHS ? launch_paths(false) : launch_lds(false);
-                    if (r) return r;
+                    if (int r = launch_k(c == 0 ? cand_a : cand_b)) return r;
                     RR_HIP(hipEventRecord(ctx->ch_ev[2 * c + 1], ctx->stream));
                 }
                 RR_HIP(hipEventSynchronize(ctx->ch_ev[3]));
@@ -1194,7 +1211,7 @@ int dispatch_impl(rr_context* ctx, uint32_t width, uint32_t height, uint32_t dep
                 ch->share = rect_share;
             }
         }
-        kernel = ch->choice == 2 ? cand_b : K_FUSED;
+        kernel = ch->choice == 2 ? cand_b : cand_a;
         // (until the measurement: the round-2 rule for launches of one or two slices -- the path-parallel kernel where the scene is small on screen)
         if (ch->choice == 0 && cand_b == K_PATHS && rect_share < 0.25) kernel = K_PATHS;
     }
@@ -1389,9 +1406,12 @@ int orbit_impl(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispat
     if ((p.flags & RR_DISPATCH_TIME_KERNEL) || !ctx->dbg_diag.empty()) lanes = 1;
     // k_render_lds is persistent -- its workgroups hold every CU until the launch is over --, so two of its launches in flight only
     // get in each other's way (sphere.obj Depth 64: 145 us per frame one at a time, 167 with two in flight)
-    if (lanes > 1 && ctx->single_identity) {
-        const rr_context::KernelChoice* c = ctx->ch_many.peek(rr_context::choice_key(width, height, p, batch < n_frames ? batch : n_frames));
-        if ((c && c->choice == 2) || ctx->dbg_kernel == 4) lanes = 1;
+    if (lanes > 1 && scene_fits_lds(ctx) && ctx->tile_world == 1) {
+        const uint32_t d = batch < n_frames ? batch : n_frames;
+        const rr_context::KernelChoice* c = ctx->ch_many.peek(rr_context::choice_key(width, height, p, d));
+        const bool alt = c && c->choice == 2;
+        const bool lds_renders = ctx->dbg_kernel == 0 ? (lds_default_depth(d) ? !alt : alt) : ctx->dbg_kernel == 4;
+        if (d >= 3u && lds_renders) lanes = 1;
     }
     if (host_out) {          // streaming to host: the copy of one region overlaps the rendering of the other
         if (ext_tiles || ctx->tile_world != 1 || (p.flags & RR_DISPATCH_FLOAT_OUTPUT))
