@@ -90,10 +90,11 @@ def pmc_busy_roofs(render_kernel, frames_per_launch):
     run inside the bench).  They were collected for k_render_fused on monkey.obj 8/2 at Depth 64 and describe nothing else:
     any other kernel or launch depth gets None."""
     import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fused_monkey_d64.txt")))
-    if not cands or render_kernel != 0 or frames_per_launch != 64:
+    tag = {0: "fused", 1: "lds"}.get(render_kernel, "none")
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s_monkey_d64.txt" % tag)))
+    if not cands or frames_per_launch != 64:
         return {"l1_texture_addresser_busy": None, "l1_data_return_busy": None, "lds_busy": None,
-                "busy_source": "PMC passes exist for k_render_fused, monkey.obj 8/2, Depth 64 only (%s); this run's shape differs"
+                "busy_source": "PMC passes exist for k_render_fused / k_render_lds, monkey.obj 8/2, Depth 64 only (%s); this run's shape differs"
                                % (os.path.relpath(cands[-1], ROOT) if cands else "none under profiles/")}
     v = {}
     for line in open(cands[-1]):
@@ -107,9 +108,8 @@ def pmc_busy_roofs(render_kernel, frames_per_launch):
                "lds_busy": round(v["SQ_ACTIVE_INST_LDS"] * 4.0 / (v["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 3)}
     except KeyError:
         return {"l1_texture_addresser_busy": None, "l1_data_return_busy": None, "lds_busy": None, "busy_source": "unparsed " + cands[-1]}
-    out["busy_source"] = ("%s: rocprofv3 --pmc passes of k_render_fused<19, 2>, monkey.obj 8/2, Depth 64 (static, the shape of this run). "
-                          "Data-return busy near 1 is not the binding roof: k_render_lds takes the node loads off that path "
-                          "entirely and is no faster on this workload (DESIGN 5.3)" % os.path.relpath(cands[-1], ROOT))
+    out["busy_source"] = ("%s: rocprofv3 --pmc passes of %s, monkey.obj 8/2, Depth 64 (static, the shape of this run)"
+                          % (os.path.relpath(cands[-1], ROOT), "k_render_lds<12, 2>" if render_kernel == 1 else "k_render_fused<19, 2>"))
     return out
 
 
