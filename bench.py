@@ -340,6 +340,7 @@ def main():
     r.load_scene(mesh.verts, mesh.indices, env)
     params = rr.default_params(max_refract=MAX_REFRACT, max_reflect=MAX_REFLECT)
     K, Wm = args.steps, args.warmup
+    timed_kernel_name = None
 
     def barrier():
         if dist is not None:
@@ -368,6 +369,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         st = r.stats()
+        timed_kernel_name = st.render_kernel_name.decode()     # the kernel that rendered the (last launch of the) timed steps
         total_rays = st.rays
         overflow = st.traversal_overflow
     else:
@@ -495,6 +497,10 @@ def main():
                     "frac_at_clock_seen": None if (model_invalid or not frac_seen or frac_seen > 1.0) else round(frac_seen, 4),
                     "model_invalid": model_invalid,
                     "kernel": kernel_name, "kernel_us": round(kernel_us, 2), "frames_per_launch": Fl,
+                    "timed_region_kernel": timed_kernel_name,
+                    "kernel_note": None if timed_kernel_name == kernel_name else
+                                   ("the timed steps ran on %s (the first launch of a shape runs its class's default kernel); the launches of this "
+                                    "record came after the kernel choice had been measured for the shape and ran on %s" % (timed_kernel_name, kernel_name)),
                     "model": "node_trips*%.1f + leaf_trips*%.1f + (shade_passes - background_waves)*%.1f + (waves - background_waves)*%.1f + "
                              "background_waves*%.1f SIMD cycles (instruction counts: profiles/%s; cycles per class and the node mix: "
                              "profiles/r03_ubench_valu.txt); %d SIMDs x %.1f GHz" % (
@@ -529,7 +535,7 @@ def main():
             v16, i16 = subdivide(mesh.verts, 2)
             r.load_scene(v16, i16, env)
             n16 = max(F, (min(K, 256) // F) * F)
-            r.render_orbit(W, H, F, angle=0.01, params=params, frames_per_dispatch=F)
+            r.render_orbit(W, H, n16, angle=0.01, params=params, frames_per_dispatch=F)      # the same shape, untimed: buffers for its launches in flight
             torch.cuda.synchronize()
             t16 = time.perf_counter()
             r.render_orbit(W, H, n16, angle=0.01, params=params, frames_per_dispatch=F)
