@@ -336,7 +336,11 @@ def main():
     assert mesh.load(asset("monkey.obj"))
     env = procedural_env(ENV_W, ENV_H, seed=0)
     r = rr.Renderer(local_rank)
-    r.set_stream(torch.cuda.current_stream().cuda_stream)       # so torch.cuda.synchronize() covers the kernels
+    # a stream of the bench's own, made torch's current one (collectives, copies and the library's launches all go through it;
+    # torch.cuda.synchronize() is device-wide and covers it): the legacy default stream synchronises with every other stream at
+    # each launch, which a 1.8 ms timed region notices
+    torch.cuda.set_stream(torch.cuda.Stream(device=torch.device("cuda", local_rank)))
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
     r.load_scene(mesh.verts, mesh.indices, env)
     params = rr.default_params(max_refract=MAX_REFRACT, max_reflect=MAX_REFLECT)
     K, Wm = args.steps, args.warmup
