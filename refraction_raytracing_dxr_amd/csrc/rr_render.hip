@@ -274,14 +274,14 @@ __global__ __launch_bounds__(256, TLAS ? 5 : 8) void k_render_paths(SceneDev sc,
 // ---------------------------------------------------------------------------------------------------
 // The same renderer with the BLAS's nodes in LDS, for meshes whose whole node array fits beside the traversal stacks
 // (the reference's meshes up to shell.obj: 24-49 KB of QNodes).  Persistent workgroups of NW waves: each copies the node
-// array into its LDS once, then every wave pulls 8x8 pixel blocks (wave-blocks, numbered exactly as k_render_fused's) from
-// ticket counters until none are left.  Why: in the L1-fed kernel the texture addresser / L1 / data-return path is the
+// array into its LDS once, then its waves draw tickets -- a few 8x8 pixel blocks each, shared inside the workgroup -- from
+// counters until none are left.  Why: in the L1-fed kernel the texture addresser / L1 / data-return path is the
 // busiest unit after the VALU (TA 84 %, TD 97 % busy, 276 cycles per request; waves spend 53 % of their life in s_waitcnt:
 // profiles/r02_pmc_fused.txt); a divergent 32-byte node costs the CU's L1 56 cycles and its LDS 25 (tools/ubench_nodefetch.hip),
 // and a lone wave's trip shrinks from an L1 round trip to an LDS one, which is what the tail of a Depth-1 launch is made of.
-// Order of work (LdsDispatch): first the blocks inside the screen rectangle of the mesh, one per ticket, then the background
-// in runs of strips.  Tickets come from LDS_QUEUES counters per phase (rr_types.h); a wave whose own queue is empty drains
-// the others, so every block is rendered whatever the placement of workgroups is.
+// Order of work (LdsDispatch): first the screen rectangle of the mesh in 32x8 strips, then everything else in 32x32 tiles.
+// Tickets come from n_queues counters per phase (rr_types.h); a wave whose own queue is empty drains the others, so every
+// block is rendered whatever the placement of workgroups is.
 // NW waves per workgroup, WGS workgroups per CU (NW * WGS / 4 waves per SIMD); stack entries are 16 bits (node index or
 // ~leaf index: an LDS-resident array has fewer than 5 120 nodes).  After the last block the last wave to leave
 // zeroes the ticket words, so the next launch on the same slot needs no memset.
@@ -692,7 +692,6 @@ hipError_t launch_render_lds(const SceneDev& sc, const DispatchDev& a, LdsDispat
     size_t lds = 0;
     const int shape = lds_kernel_shape(q.node_bytes, q.stack_entries, &lds, min_shape);
     if (shape < 0) return hipErrorInvalidValue;
-    q.wave_blocks = a.n_blocks * 4u;
     {   // one queue per workgroup of the shape that will run (never more than LDS_QUEUES)
         static const int wgs[] = { 2, 2, 1 };
         const uint32_t grid = (uint32_t)n_cus * (uint32_t)wgs[shape];
@@ -700,7 +699,6 @@ hipError_t launch_render_lds(const SceneDev& sc, const DispatchDev& a, LdsDispat
         if (q.n_queues > LDS_QUEUES) q.n_queues = LDS_QUEUES;
         if (q.n_queues < 1u) q.n_queues = 1u;
     }
-    q.p2_strips = 1u;
     q.p2_tickets = a.n_local_tiles * a.n_frames;        // phase 2: one 32x32 tile of one slice per ticket (blocks inside the rectangle are skipped)
     // phase 1: the rectangle, widened to whole 32-pixel columns, in 32x8 strips of one slice each
     if (q.rx1 > q.rx0 && q.ry1 > q.ry0) {
@@ -709,7 +707,6 @@ hipError_t launch_render_lds(const SceneDev& sc, const DispatchDev& a, LdsDispat
     }
     const bool rect = q.rx1 > q.rx0 && q.ry1 > q.ry0;
     q.rect_bw = rect ? (q.rx1 - q.rx0) / 8u : 0u;
-    q.p1_direct = 1u;
     q.p1_tickets = !rect ? 0u : (q.rect_bw / 4u) * ((q.ry1 - q.ry0) / 8u) * a.n_frames;
     if ((uint64_t)q.p2_tickets * a.n_frames >= 0xffffffffull || (uint64_t)q.p1_tickets * a.n_frames >= 0xffffffffull) return hipErrorInvalidValue;   // (multiply-high divisions)
     q.div_frames = (uint32_t)(0x100000000ull / a.n_frames) + 1u;

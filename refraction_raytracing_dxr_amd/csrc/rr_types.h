@@ -142,23 +142,17 @@ struct DispatchDev {
 };
 
 // k_render_lds (persistent workgroups, BLAS nodes in LDS): the work queues of one launch.
-// Work is handed out in two phases.  Phase 1 (launches of few slices, whose length is set by their most expensive blocks):
-// the 8x8 pixel blocks inside the screen rectangle that bounds the mesh in every slice of the launch (the projection of the
-// BLAS bounds, computed by the host from the slices' constants), one block per ticket -- these hold every secondary ray,
-// i.e. every expensive block, and start first so that the launch does not end on them.  Phase 2: every 32x8 strip of the
-// dispatch in image order, slices interleaved, one per ticket, minus the blocks phase 1 rendered.  Launches of many slices
-// have no phase 1: image order mixes cheap background blocks (arithmetic only) with mesh blocks (LDS traffic) on every CU,
-// which is worth more than an early start of the expensive ones (monkey.obj, Depth 64: 3.9 % of wave time idle at the end).
+// Work is handed out in two phases, a ticket at a time; the wave that draws a ticket shares its blocks with its workgroup
+// through LDS (rr_render.hip).  Phase 1: the screen rectangle that bounds the mesh in every slice of the launch (the projection
+// of the BLAS bounds, computed by the host from the slices' constants, widened to 32-pixel columns) in 32x8 strips of one slice
+// each -- these hold every secondary ray, i.e. every expensive block, and start first.  Phase 2: every 32x32 tile of every
+// slice in image order, minus the blocks phase 1 rendered: the background, a microsecond per block, sixteen blocks per ticket.
 struct LdsDispatch {
-    uint32_t* tickets;          // LDS_TICKET_WORDS words, one counter per 64-byte line: phase 1 queues, phase 2 queues, finished waves
-    uint32_t p1_tickets;        // phase 1: rect blocks * slices (direct) or all wave-blocks (scan), see p1_direct
-    uint32_t p1_direct;         // 1: ticket t is slice t % n_frames of rect block t / n_frames (unsharded raster frames);
-                                // 0: ticket t is wave-block t of the dispatch, rendered only if it lies inside the rectangle
-    uint32_t rect_bw;           // rectangle width in 8x8 blocks
-    uint32_t rx0, ry0, rx1, ry1;// the rectangle in pixels, multiples of 8 (rx1 <= rx0: empty)
-    uint32_t p2_tickets;        // phase 2: strips of the dispatch
-    uint32_t p2_strips;         // 1
-    uint32_t wave_blocks;       // 4 per 32x8 strip block of the dispatch
+    uint32_t* tickets;          // LDS_TICKET_WORDS words, one counter per 64-byte line: phase 1 queues, phase 2 queues, finished workgroups
+    uint32_t p1_tickets;        // phase 1: strips of the rectangle * slices; ticket t is slice t % n_frames of strip t / n_frames
+    uint32_t rect_bw;           // rectangle width in 8x8 blocks (a multiple of 4)
+    uint32_t rx0, ry0, rx1, ry1;// the rectangle in pixels: x multiples of 32, y multiples of 8 (rx1 <= rx0: empty)
+    uint32_t p2_tickets;        // phase 2: tiles * slices; ticket t is slice t % n_frames of tile t / n_frames
     uint32_t n_queues;          // ticket queues per phase in use (<= LDS_QUEUES)
     uint32_t home_xcc;          // 1: a wave's first queue is its XCD's number, 0: its own number, modulo n_queues
     uint32_t* park;             // parked reflected rays: [wave of the grid][park_slots][8 words][64 lanes]
@@ -168,13 +162,11 @@ struct LdsDispatch {
     uint32_t div_frames, div_tiles_x, div_per_row;   // 2^32 / d + 1 for d = n_frames, tiles_x, strips per rectangle row: x / d == umulhi(x, div) for x * d < 2^32
 };
 // Ticket counters: ticket u belongs to queue u % n_queues; a wave starts on the queue of its XCD's number and, once that
-// is empty, looks through the other counters 64 at a time (plain loads past the L1: a counter only ever grows, so a queue
-// seen empty stays empty) and drains those that are not.  Eight queues are the product setting: an XCD then keeps to every
-// eighth strip and slice, which its L2 rewards, and k_render_lds is only used for launches of 32 slices and more, where the
-// cost of 768 waves sharing a word does not show (a word takes about 88 returning atomics per microsecond under a few
-// contenders, MI355X_MICROARCH.md "dequeue", far fewer under hundreds: a Depth-1 launch of primary rays alone takes 294 us
-// with 8 queues, 132 with 32, 107 with 64 -- and 58 with k_render_fused, which the hardware dispatcher feeds and which
-// therefore renders the launches of few slices).  RR_DEBUG_TICKET +64 / +128 select 64 / 512 queues for experiments.
+// is empty, goes through the others one by one, each looked at with a plain load before it is drawn from (a counter only ever
+// grows, so a queue seen empty stays empty).  Eight queues are the product setting: with a number of slices that is a multiple
+// of eight an XCD then keeps to every eighth slice, which its L2 rewards (a word takes about 88 returning atomics per
+// microsecond, MI355X_MICROARCH.md "dequeue": ~600 tickets per microsecond over eight).  RR_DEBUG_TICKET +64 / +128 select
+// 64 / 512 queues for experiments.
 constexpr uint32_t LDS_QUEUES = 512;
 constexpr uint32_t LDS_TICKET_WORDS = (2 * LDS_QUEUES + 1) * 16;
 
