@@ -34,8 +34,6 @@ __global__ __launch_bounds__(256, WPS ? WPS : TLAS ? RR_TLAS_WAVES_PER_SIMD(STAC
     const uint32_t x = bp.x0 + lx, y = bp.y0 + ly;
     const bool valid = bp.tile_ok && x < a.W && y < a.H;
     const CamDev& cb = a.cams[bp.frame];                              // wave-uniform: scalar loads
-    uint32_t* const out_rgba8 = bp.bg ? a.out_bg + (size_t)bp.frame * a.bg_stride : a.out_rgba8 + (size_t)bp.frame * a.frame_stride;
-    float4* const out_f32 = a.out_f32 ? a.out_f32 + (size_t)bp.frame * a.frame_stride : nullptr;
 
     LaneStats st;
     stats_clock_begin<STATS>(st);
@@ -58,9 +56,23 @@ __global__ __launch_bounds__(256, WPS ? WPS : TLAS ? RR_TLAS_WAVES_PER_SIMD(STAC
             RegPark<PEND> park;
             acc = render_pixel<STATS, TLAS, DIAG, E, GlobalNodes>(sc, a, cb, x, y, true, stk, GlobalNodes{}, park, st, Diag{ &diag_trips[wave], 4 });
         }
-        const size_t o = a.compact_out == 0u ? (size_t)y * a.W + x
-                                            : (size_t)bp.tile_local * (TILE * TILE) + (bp.py0 + ly) * TILE + (bp.px0 + lx);
-        store_pixel(a, out_rgba8, out_f32, o, acc);
+        // What the store needs is read from the kernel's argument block AGAIN here instead of being kept across the renderer:
+        // the renderer keeps ~70 scalars live, the compiler allows itself 80 at eight waves per SIMD and moves the rest through
+        // vector lanes -- 43 vector instructions per wave before this, 13 now.  (Arguments lie in the block in order, each at
+        // its own alignment: `a` follows `sc`.  The asm keeps the compiler from recognising the loads as the ones it already
+        // did at the top; every frame-parity test would fail on a wrong offset.)
+        typedef const __attribute__((address_space(4))) DispatchDev* KA;
+        KA ap = (KA)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() +
+                     ((sizeof(SceneDev) + alignof(DispatchDev) - 1) / alignof(DispatchDev)) * alignof(DispatchDev));
+        asm volatile("" : "+s"(ap));
+        const uint32_t k_compact = ap->compact_out, k_W = ap->W, k_tonemap = ap->tonemap;
+        const size_t o = k_compact == 0u ? (size_t)y * k_W + x
+                                         : (size_t)bp.tile_local * (TILE * TILE) + (bp.py0 + ly) * TILE + (bp.px0 + lx);
+        uint32_t* const out_rgba8 = bp.bg ? ap->out_bg + (size_t)bp.frame * ap->bg_stride : ap->out_rgba8 + (size_t)bp.frame * ap->frame_stride;
+        float4* const out_f32 = ap->out_f32 ? ap->out_f32 + (size_t)bp.frame * ap->frame_stride : nullptr;
+        DispatchDev a2;
+        a2.tonemap = k_tonemap; a2.compact_out = k_compact;
+        store_pixel(a2, out_rgba8, out_f32, o, acc);
     }
 
     if (DIAG) {

@@ -150,9 +150,12 @@ struct DispatchDev {
 struct LdsDispatch {
     uint32_t* tickets;          // LDS_TICKET_WORDS words, one counter per 64-byte line: phase 1 queues, phase 2 queues, finished workgroups
     uint32_t p1_tickets;        // phase 1: strips of the rectangle * slices; ticket t is slice t % n_frames of strip t / n_frames
+    uint32_t pad0;              // (the layout of this block decides which arguments the compiler fetches together, and with that how
+                                //  many scalars k_render_lds moves through vector lanes: 49 with these three words in place, 223 without)
     uint32_t rect_bw;           // rectangle width in 8x8 blocks (a multiple of 4)
     uint32_t rx0, ry0, rx1, ry1;// the rectangle in pixels: x multiples of 32, y multiples of 8 (rx1 <= rx0: empty)
     uint32_t p2_tickets;        // phase 2: tiles * slices; ticket t is slice t % n_frames of tile t / n_frames
+    uint32_t pad1, pad2;
     uint32_t n_queues;          // ticket queues per phase in use (<= LDS_QUEUES)
     uint32_t home_xcc;          // 1: a wave's first queue is its XCD's number, 0: its own number, modulo n_queues
     uint32_t* park;             // parked reflected rays: [wave of the grid][park_slots][8 words][64 lanes]
