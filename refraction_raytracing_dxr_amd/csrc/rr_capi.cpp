@@ -1406,12 +1406,14 @@ int orbit_impl(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispat
     if ((p.flags & RR_DISPATCH_TIME_KERNEL) || !ctx->dbg_diag.empty()) lanes = 1;
     // k_render_lds is persistent -- its workgroups hold every CU until the launch is over --, so two of its launches in flight only
     // get in each other's way (sphere.obj Depth 64: 145 us per frame one at a time, 167 with two in flight)
-    if (lanes > 1 && scene_fits_lds(ctx) && ctx->tile_world == 1) {
+    bool one_kernel_at_a_time = false;
+    if (scene_fits_lds(ctx) && ctx->tile_world == 1) {
         const uint32_t d = batch < n_frames ? batch : n_frames;
         const rr_context::KernelChoice* c = ctx->ch_many.peek(rr_context::choice_key(width, height, p, d));
         const bool alt = c && c->choice == 2;
         const bool lds_renders = ctx->dbg_kernel == 0 ? (lds_default_depth(d) ? !alt : alt) : ctx->dbg_kernel == 4;
-        if (d >= 3u && lds_renders) lanes = 1;
+        one_kernel_at_a_time = d >= 3u && lds_renders;
+        if (lanes > 1 && one_kernel_at_a_time) lanes = 1;
     }
     if (host_out) {          // streaming to host: the copy of one region overlaps the rendering of the other
         if (ext_tiles || ctx->tile_world != 1 || (p.flags & RR_DISPATCH_FLOAT_OUTPUT))
@@ -1449,7 +1451,12 @@ int orbit_impl(rr_context* ctx, uint32_t width, uint32_t height, const rr_dispat
         const uint32_t d = n_frames - k < batch ? n_frames - k : batch;
         uint32_t* ext = ext_tiles ? ext_tiles + (size_t)k * ext_stride_elems : nullptr;
         ctx->stream = ctx->lane_stream[b % lanes];
-        rc = dispatch_impl(ctx, width, height, d, ctx->d_cams + k, cams.data() + k, p, ext, ext_stride_elems, true, b % lanes, batch);
+        // (streaming to host keeps two regions for the copies' sake; the persistent kernel's launches still go one after the other)
+        if (one_kernel_at_a_time && b > 0 && hipStreamWaitEvent(ctx->stream, ctx->lane_fork[(b - 1) % lanes], 0) != hipSuccess)
+            rc = fail(ctx, RR_ERR_DEVICE, "render_orbit: lane order");
+        if (rc == RR_OK) rc = dispatch_impl(ctx, width, height, d, ctx->d_cams + k, cams.data() + k, p, ext, ext_stride_elems, true, b % lanes, batch);
+        if (rc == RR_OK && one_kernel_at_a_time && hipEventRecord(ctx->lane_fork[b % lanes], ctx->stream) != hipSuccess)
+            rc = fail(ctx, RR_ERR_DEVICE, "render_orbit: lane order");
         if (rc == RR_OK && host_out) {      // same lane: the region is not rendered into again before this copy is done
             const size_t fb = (size_t)width * height * 4;
             hipError_t e = hipMemcpyAsync(host_out + (size_t)k * fb, ctx->d_rgba8 + ctx->frame_base, (size_t)d * fb, hipMemcpyDeviceToHost, ctx->stream);
