@@ -171,7 +171,7 @@ struct rr_context {
     bool dbg_async_set = false;
     uint32_t dbg_async[2] = { 2, 2 };    // RR_DEBUG_ASYNC="step,shade": issue thresholds of k_stream_rays in sixteenths of the live lanes
     bool dbg_tile_order = true;      // RR_DEBUG_TILE_ORDER=0: tiles in image order (DispatchDev::rt_*)
-    int  dbg_stream_waves = 6;       // RR_DEBUG_STREAM_WAVES: waves per SIMD k_stream_rays is built for (5..8)
+    int  dbg_stream_waves = 6;       // (the stream renderer's waves per SIMD are a build-time constant now: -DRR_STREAM_WPS)
     bool dbg_tlas32 = false;         // RR_DEBUG_TLAS32: two-level scenes keep 32-bit stack entries and register-parked rays
     int  dbg_shape = 0;              // RR_DEBUG_SHAPE: first k_render_lds workgroup shape to consider (rr_launch.h)
     std::string dbg_diag;            // RR_DEBUG_DIAG: file that receives per-wave diagnostics of Depth-1 dispatches
@@ -425,7 +425,6 @@ int rr_create(int device_ordinal, rr_context** out)
     if (const char* e = getenv("RR_DEBUG_TICKET")) ctx->dbg_ticket_blocks = atoi(e);
     if (const char* e = getenv("RR_DEBUG_SHAPE")) ctx->dbg_shape = atoi(e);
     if (const char* e = getenv("RR_DEBUG_TLAS32")) ctx->dbg_tlas32 = atoi(e) != 0;
-    if (const char* e = getenv("RR_DEBUG_STREAM_WAVES")) ctx->dbg_stream_waves = atoi(e);
     if (const char* e = getenv("RR_DEBUG_TILE_ORDER")) ctx->dbg_tile_order = atoi(e) != 0;
     if (const char* e = getenv("RR_DEBUG_ASYNC")) { unsigned l = 2, sh = 2; if (sscanf(e, "%u,%u", &l, &sh) == 2 && l >= 1 && sh >= 1) { ctx->dbg_async[0] = l; ctx->dbg_async[1] = sh; ctx->dbg_async_set = true; } }
     if (const char* e = getenv("RR_DEBUG_DIAG")) ctx->dbg_diag = e;

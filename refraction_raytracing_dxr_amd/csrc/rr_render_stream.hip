@@ -542,15 +542,11 @@ static hipError_t launch_stream_sw(const SceneDev& sc, const DispatchDev& a, con
 hipError_t launch_render_stream(const SceneDev& sc, const DispatchDev& a, const StreamDev& s, int stack, uint32_t n_wg, bool stats, hipStream_t st, int waves)
 {
     if (a.n_blocks == 0) return hipSuccess;
-    // (waves: waves per SIMD the ray kernels are built for; RR_DEBUG_STREAM_WAVES, experiments)
-    if (stack <= 30) {
-        if (stats) return launch_stream_sw<30, true, RR_STREAM_WPS>(sc, a, s, n_wg, st);
-        if (waves == 8) return launch_stream_sw<30, false, 8>(sc, a, s, n_wg, st);
-        if (waves == 7) return launch_stream_sw<30, false, 7>(sc, a, s, n_wg, st);
-        if (waves == 5) return launch_stream_sw<30, false, 5>(sc, a, s, n_wg, st);
-        return launch_stream_sw<30, false, 6>(sc, a, s, n_wg, st);
-    }
-    return stats ? launch_stream_sw<39, true, 6>(sc, a, s, n_wg, st) : launch_stream_sw<39, false, 6>(sc, a, s, n_wg, st);
+    // (built for six waves per SIMD: the eight-wave build spilled into every loop header, those for seven and five measured up to
+    // 8 % slower on C5 when the kernel was tuned; -DRR_STREAM_WPS=<n> rebuilds it for another number)
+    (void)waves;
+    if (stack <= 30) return stats ? launch_stream_sw<30, true, RR_STREAM_WPS>(sc, a, s, n_wg, st) : launch_stream_sw<30, false, RR_STREAM_WPS>(sc, a, s, n_wg, st);
+    return stats ? launch_stream_sw<39, true, RR_STREAM_WPS>(sc, a, s, n_wg, st) : launch_stream_sw<39, false, RR_STREAM_WPS>(sc, a, s, n_wg, st);
 }
 
 } // namespace rr

@@ -3,4 +3,4 @@
 # node loop needs twice as many --, a shading pass once shade/16 of them are finished)
 mkdir -p gpurun_out
 which=${1:-C5}
-for w in 6; do for a in 2,6 1,6 1,4 2,4 3,6 2,8 3,8 1,8; do echo "waves $w async $a: $(RR_DEBUG_KERNEL=stream RR_DEBUG_STREAM_WAVES=$w RR_DEBUG_ASYNC=$a timeout -k 10 100 python tools/exp_tlas.py $which 2 2>&1 | tail -1 | cut -c1-60,150-330)"; done; done
+for w in 6; do for a in 2,6 1,6 1,4 2,4 3,6 2,8 3,8 1,8; do echo "waves $w async $a: $(RR_DEBUG_KERNEL=stream RR_DEBUG_ASYNC=$a timeout -k 10 100 python tools/exp_tlas.py $which 2 2>&1 | tail -1 | cut -c1-60,150-330)"; done; done
